@@ -1,0 +1,130 @@
+/* libunet_hip.so -- C ABI of the MI355X-native UNet3d conv engine.
+ *
+ * This is the drop-in boundary under the reference's UNet3d operator surface: a host (the C++
+ * `UNet3dImpl` of include/unet.hpp, or the Python mirror in unet-studio_amd/) owns parameters,
+ * gradients and the workspace as device memory and drives the engine through these calls.  No
+ * torch types cross this boundary: plain pointers, sizes and a hipStream_t (passed as void*).
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *   unet_init / unet_device_info     cuda.cu:34-74 (check_cuda device enumeration)
+ *   unet_plan_create                 UNet3dImpl::UNet3dImpl + create_layer        unet.cpp:24-166
+ *   unet_plan_param_* / buffer_*     parameters()/buffers() order and shapes      unet.cpp:130,160-164; main.cpp:193-204
+ *   unet_forward                     UNet3dImpl::forward (libtorch conv/norm/...)  unet.cpp:168-193; callers train.cpp:628,840,
+ *                                    evaluate.cpp:226, qc.cpp:88
+ *   unet_backward                    autograd backward of forward                 train.cpp:706
+ *   unet_loss                        calc_losses + deep-supervision loop          train.cpp:501-552,634-706
+ *   unet_sgd_step                    /batch_size, clip_grad_norm_(12), SGD step   train.cpp:759-766; unet.cpp:246-277
+ *   unet_op_*                        single libtorch modules (unit-test surface)  unet.cpp:38-98
+ *
+ * All functions return 0 on success, non-zero on error; unet_last_error() returns a thread-local
+ * message (the C++ host rethrows it as std::runtime_error so the reference's catch blocks at
+ * train.cpp:709-721,1134 keep working).  All device pointers must live on the plan's device.
+ * Calls on one plan are re-entrant as long as each concurrent call has its own workspace and stream
+ * (qc.cpp:273-297 calls forward on one model from several threads).
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_DTYPE_F32 0  /* activations, gradients and arithmetic in fp32 (parity configuration) */
+#define UNET_DTYPE_BF16 1 /* activations/gradients bf16, fp32 accumulate, fp32 master parameters */
+
+#define UNET_IMPL_AUTO 0    /* MFMA kernels where the shape allows, direct kernels elsewhere */
+#define UNET_IMPL_DIRECT 1  /* direct (non-MFMA) HIP kernels only */
+
+typedef struct unet_plan unet_plan;
+
+const char* unet_last_error(void);
+
+/* device enumeration (cuda.cu:34-74) */
+int unet_init(int* n_devices);
+int unet_device_info(int device, char* name, size_t name_len, size_t* total_mem, int* compute_units, int* gcn_arch_is_gfx950);
+
+/* Plan: the parsed architecture DSL bound to one input size, dtype and device.
+ * arch_dsl: text of UNet3dImpl::architecture; in_c/out_c: in_count/out_count; D,H,W: input volume
+ * (tensor {1,in_c,D,H,W}, x fastest).  Fails with the reference's messages for DSL errors. */
+int unet_plan_create(const char* arch_dsl, int in_c, int out_c, int D, int H, int W, int dtype, int device, int impl,
+                     unet_plan** out);
+void unet_plan_destroy(unet_plan* plan);
+
+/* parameters() order (unet.cpp:130,160-164).  dims has room for 5 entries. */
+int unet_plan_param_count(const unet_plan* plan, int* n);
+int unet_plan_param_shape(const unet_plan* plan, int i, int64_t dims[5], int* ndim);
+/* 1 if weight decay applies to parameter i (unet.cpp:254: dim > 1 and no "bias" in the name) */
+int unet_plan_param_decay(const unet_plan* plan, int i, int* decay);
+/* fan_in of parameter i's owning conv (0 for norm affine): default-init bound 1/sqrt(fan_in) */
+int unet_plan_param_fan_in(const unet_plan* plan, int i, int64_t* fan_in, int* is_norm_weight);
+/* buffers() order: per bnorm layer running_mean[C], running_var[C] (fp32) ; num_batches_tracked is host-side */
+int unet_plan_buffer_count(const unet_plan* plan, int* n);
+int unet_plan_buffer_shape(const unet_plan* plan, int i, int64_t* numel);
+/* outputs: one per decoder level, [0] = full resolution; dims = {1,C,D,H,W}; C = 0 when the level has no head */
+int unet_plan_output_count(const unet_plan* plan, int* n);
+int unet_plan_output_shape(const unet_plan* plan, int level, int64_t dims[5]);
+int unet_plan_workspace_bytes(const unet_plan* plan, size_t* bytes);
+/* algorithmic conv + conv-transpose FLOPs (2*MAC) of one forward, and of backward (dgrad + wgrad) */
+int unet_plan_flops(const unet_plan* plan, double* fwd, double* bwd);
+/* human-readable op list of the lowered graph (for print_layers()/debugging); returns needed length */
+size_t unet_plan_describe(const unet_plan* plan, char* buf, size_t len);
+
+/* forward.  params: host array of device pointers (fp32, parameters() order).  buffers: host array of
+ * device pointers (fp32 running_mean/running_var pairs) or NULL when the architecture has no bnorm.
+ * x: fp32 {1,in_c,D,H,W}.  outs: host array of device pointers, fp32 {1,out_c,D>>l,H>>l,W>>l} per level
+ * (NULL entries are skipped).  mode: 0 = eval (bnorm uses running stats: train.cpp:834-840, and after
+ * prepare_for_inference y = gamma*x+beta), 1 = train (batch statistics, running stats updated).
+ * workspace: unet_plan_workspace_bytes() bytes; after a mode-1 forward it holds what backward needs. */
+int unet_forward(const unet_plan* plan, const float* const* params, float* const* buffers, const float* x,
+                 float* const* outs, void* workspace, int mode, void* stream);
+
+/* backward of the last mode-1 forward on this workspace.  grad_outs: fp32 dL/d(outs[l]) or NULL (= no
+ * loss on that level).  grad_params: fp32, parameters() order, ACCUMULATED (+=) as .grad is across the
+ * batch_size micro-steps of one optimizer step (train.cpp:604-606,706).  grad_x: optional fp32 dL/dx. */
+int unet_backward(const unet_plan* plan, const float* const* params, const float* const* grad_outs,
+                  float* const* grad_params, float* grad_x, void* workspace, void* stream);
+
+/* calc_losses over all deep-supervision levels (train.cpp:501-552,634-706).
+ * target: int64 {1,D,H,W} labels (values >= out_c are masked out); cost_mask bit0 ce, bit1 dice, bit2 mse
+ * (0 behaves as ce only: train.cpp:696-697); collapse_before as calc_losses.
+ * losses_out (device, 4 floats): {total, ce0, dice0, mse0}.  grad_outs[l] (may be NULL = no gradient
+ * wanted) receives dL_total/d(outs[l]).  scratch: unet_loss_scratch_bytes() bytes. */
+int unet_loss_scratch_bytes(const unet_plan* plan, size_t* bytes);
+int unet_loss(const unet_plan* plan, const float* const* outs, const int64_t* target, int cost_mask, int collapse_before,
+              float* const* grad_outs, float* losses_out, void* scratch, void* stream);
+
+/* step epilogue over flat buffers (train.cpp:759-766 + SGD(momentum, nesterov, weight decay) of
+ * unet.cpp:254-275): g *= grad_scale (1/batch_size); coef = min(1, clip_norm/(||g||+1e-6));
+ * d = coef*g + wd*p (wd only on decay parameters); m = momentum*m + d; p -= lr*(d + momentum*m) (nesterov)
+ * or lr*m; g = 0.  params/grads/momentum are flat fp32 buffers holding the tensors in parameters()
+ * order, contiguous.  norm_out (device, 1 float) receives ||g|| before clipping.  scratch: 64 KiB. */
+int unet_sgd_step(const unet_plan* plan, float* params_flat, float* grads_flat, float* momentum_flat, float lr,
+                  float momentum, int nesterov, float weight_decay, float clip_norm, float grad_scale, float* norm_out,
+                  void* scratch, void* stream);
+
+/* ---- single-op surface (unit tests, parity per kernel).  Activations are channels-last [D][H][W][C]
+ * in the element type of `dtype`; weights/bias/grads fp32 in torch layout ([Cout,Cin,k,k,k]; conv_trans
+ * [Cin,Cout,2,2,2]).  impl: UNET_IMPL_*.  scratch: at least unet_op_scratch_bytes() bytes. ---- */
+int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes);
+int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D,
+                       int H, int W, int ks, int stride, void* scratch, void* stream);
+int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H,
+                            int W, int ks, int stride, void* scratch, void* stream);
+int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout,
+                              int D, int H, int W, int ks, int stride, void* scratch, void* stream);
+int unet_op_convt_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D,
+                      int H, int W, void* scratch, void* stream);
+int unet_op_convt_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H,
+                           int W, void* scratch, void* stream);
+int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout,
+                             int D, int H, int W, void* scratch, void* stream);
+/* layout helpers: fp32 NCDHW <-> channels-last element type */
+int unet_op_pack_ndhwc(int dtype, const float* x_ncdhw, void* y_ndhwc, int C, int64_t S, void* stream);
+int unet_op_unpack_ncdhw(int dtype, const void* x_ndhwc, float* y_ncdhw, int C, int64_t S, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,291 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the oracle and the golden vectors.
+Tolerances: fp32 engine 1e-4 relative (north_star: logits within 1e-4 rel of the CPU reference);
+bf16 engine: its own measured error, bounded here at 4e-2 relative (8 mantissa bits through ~12 layers)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import unet_studio_amd as U  # noqa: E402
+from oracle import aten_ref as A  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+E = U.engine
+DEV = "cuda:0"
+TOL = {"fp32": 1e-4, "bf16": 4e-2}
+TDT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+EDT = {"fp32": U.DTYPE_F32, "bf16": U.DTYPE_BF16}
+
+
+def rel(a, b, scale=None):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = float(np.abs(b).max()) if scale is None else scale
+    return float(np.abs(a - b).max()) / max(scale, 1e-30)
+
+
+def stream():
+    return torch.cuda.current_stream(DEV).cuda_stream
+
+
+def to_cl(x, dt):  # numpy [C,D,H,W] -> device channels-last [D,H,W,C]
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 2, 3, 0)))).to(DEV).to(TDT[dt]).contiguous()
+
+
+def from_cl(t):  # device [D,H,W,C] -> numpy [C,D,H,W] fp32
+    return np.ascontiguousarray(np.transpose(t.float().cpu().numpy(), (3, 0, 1, 2)))
+
+
+def scratch(cin, cout):
+    b = C.c_size_t()
+    E.check(E.lib.unet_op_scratch_bytes(cin, cout, 1, 1, 1, C.byref(b)))
+    return torch.empty(b.value, dtype=torch.uint8, device=DEV)
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def q(x, dt):  # what the engine sees after rounding its input to the element type
+    return x if dt == "fp32" else torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+
+
+CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
+    (1, 16, (9, 10, 12), 3, 1), (16, 16, (8, 8, 16), 3, 1), (5, 7, (6, 7, 9), 3, 1), (16, 32, (8, 10, 12), 3, 2),
+    (3, 4, (7, 9, 11), 3, 2), (16, 6, (5, 6, 7), 1, 1), (32, 16, (4, 8, 16), 3, 1), (24, 40, (5, 5, 6), 3, 1),
+]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("impl", [U.IMPL_DIRECT, U.IMPL_AUTO])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_ops(case, dt, impl):
+    cin, cout, (D, H, W), ks, st = case
+    l = O.lib()
+    x = q(rnd((cin, D, H, W), 1), dt); w = rnd((cout, cin, ks, ks, ks), 2, 0.2); b = rnd((cout,), 3)
+    pad = (ks - 1) // 2
+    od = [(s + 2 * pad - ks) // st + 1 for s in (D, H, W)]
+    y_ref = np.empty((cout, *od), np.float32)
+    l.orc_conv3d_fwd(O._f(x), O._f(w), O._f(b), O._f(y_ref), cin, cout, D, H, W, ks, st)
+    sc = scratch(cin, cout)
+    wd, bd = torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV)
+    xd = to_cl(x, dt)
+    yd = torch.empty((*od, cout), dtype=TDT[dt], device=DEV)
+    E.check(E.lib.unet_op_conv3d_fwd(EDT[dt], impl, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), cin, cout, D, H, W,
+                                     ks, st, sc.data_ptr(), stream()))
+    assert rel(from_cl(yd), y_ref) < (1e-5 if dt == "fp32" else 1e-2)
+    # dgrad / wgrad
+    dy = q(rnd((cout, *od), 4), dt)
+    dx_ref = np.empty_like(x); dw_ref = np.zeros_like(w); db_ref = np.zeros_like(b)
+    l.orc_conv3d_bwd_data(O._f(dy), O._f(w), O._f(dx_ref), cin, cout, D, H, W, ks, st)
+    l.orc_conv3d_bwd_weight(O._f(x), O._f(dy), O._f(dw_ref), O._f(db_ref), cin, cout, D, H, W, ks, st)
+    dyd = to_cl(dy, dt)
+    dxd = torch.empty((D, H, W, cin), dtype=TDT[dt], device=DEV)
+    E.check(E.lib.unet_op_conv3d_bwd_data(EDT[dt], impl, dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), cin, cout, D, H, W, ks, st,
+                                          sc.data_ptr(), stream()))
+    assert rel(from_cl(dxd), dx_ref) < (1e-5 if dt == "fp32" else 1e-2)
+    dwd = torch.ones_like(wd); dbd = torch.ones_like(bd)  # += semantics: start from 1
+    E.check(E.lib.unet_op_conv3d_bwd_weight(EDT[dt], impl, xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), cin, cout,
+                                            D, H, W, ks, st, sc.data_ptr(), stream()))
+    assert rel(dwd.cpu().numpy() - 1.0, dw_ref) < (2e-5 if dt == "fp32" else 1e-2)
+    assert rel(dbd.cpu().numpy() - 1.0, db_ref) < (2e-5 if dt == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(16, 16, (4, 5, 6)), (7, 3, (3, 4, 5)), (32, 16, (4, 4, 8))])
+def test_convt_ops(case, dt):
+    cin, cout, (D, H, W) = case
+    l = O.lib()
+    x = q(rnd((cin, D, H, W), 1), dt); w = rnd((cin, cout, 2, 2, 2), 2, 0.3); b = rnd((cout,), 3)
+    y_ref = np.empty((cout, 2 * D, 2 * H, 2 * W), np.float32)
+    l.orc_convt_fwd(O._f(x), O._f(w), O._f(b), O._f(y_ref), cin, cout, D, H, W)
+    sc = scratch(cin, cout)
+    wd, bd, xd = torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV), to_cl(x, dt)
+    yd = torch.empty((2 * D, 2 * H, 2 * W, cout), dtype=TDT[dt], device=DEV)
+    E.check(E.lib.unet_op_convt_fwd(EDT[dt], 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), cin, cout, D, H, W,
+                                    sc.data_ptr(), stream()))
+    assert rel(from_cl(yd), y_ref) < (1e-5 if dt == "fp32" else 1e-2)
+    dy = q(rnd(y_ref.shape, 4), dt)
+    dx_ref = np.empty_like(x); dw_ref = np.zeros_like(w); db_ref = np.zeros_like(b)
+    l.orc_convt_bwd_data(O._f(dy), O._f(w), O._f(dx_ref), cin, cout, D, H, W)
+    l.orc_convt_bwd_weight(O._f(x), O._f(dy), O._f(dw_ref), O._f(db_ref), cin, cout, D, H, W)
+    dyd = to_cl(dy, dt)
+    dxd = torch.empty((D, H, W, cin), dtype=TDT[dt], device=DEV)
+    E.check(E.lib.unet_op_convt_bwd_data(EDT[dt], 0, dyd.data_ptr(), wd.data_ptr(), dxd.data_ptr(), cin, cout, D, H, W,
+                                         sc.data_ptr(), stream()))
+    assert rel(from_cl(dxd), dx_ref) < (1e-5 if dt == "fp32" else 1e-2)
+    dwd = torch.zeros_like(wd); dbd = torch.zeros_like(bd)
+    E.check(E.lib.unet_op_convt_bwd_weight(EDT[dt], 0, xd.data_ptr(), dyd.data_ptr(), dwd.data_ptr(), dbd.data_ptr(), cin, cout,
+                                           D, H, W, sc.data_ptr(), stream()))
+    assert rel(dwd.cpu().numpy(), dw_ref) < (2e-5 if dt == "fp32" else 1e-2)
+    assert rel(dbd.cpu().numpy(), db_ref) < (2e-5 if dt == "fp32" else 1e-2)
+
+
+def load_case(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    n = len([k for k in d.files if k.startswith("param") and not k.startswith("param_")])
+    return d, n
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["cfg1_bnorm_16", "mix_16", "c16_24"])
+def test_network_against_golden(golden_dir, name, dt):
+    """forward logits, fused losses, every parameter gradient, running stats, one optimizer step, both eval modes"""
+    d, n = load_case(golden_dir, name)
+    arch, cin, cout = str(d["arch"]), int(d["cin"]), int(d["cout"])
+    tol = TOL[dt]
+    m = U.UNet3d(cin, cout, arch, device=DEV, dtype=dt)
+    m.load_parameters([d["param%d" % i] for i in range(n)])
+    x = torch.from_numpy(d["x"])[None].to(DEV)
+    t = torch.from_numpy(d["target"])[None].to(DEV)
+    m.train()
+    plan = m.plan_for(x.shape[2:]); ws = m._workspace(plan)
+    outs = m._run_forward(plan, ws, x, 1)
+    k = 0
+    while "logits%d" % k in d.files:
+        assert rel(outs[k][0].cpu().numpy(), d["logits%d" % k]) < tol, "logits level %d" % k
+        k += 1
+    losses, gouts = m.loss(outs, t)
+    lo = losses.cpu().numpy()
+    assert abs(lo[0] - float(d["loss"])) < tol * max(1.0, float(d["loss"]))
+    assert np.allclose(lo[1:], d["stats"], rtol=tol, atol=tol)
+    m._run_backward(plan, ws, gouts)
+    gmax = max(float(np.abs(d["grad%d" % i]).max()) for i in range(n))
+    gt = 2e-4 if dt == "fp32" else 8e-2
+    for i, g in enumerate(m.grads()):
+        assert rel(g.cpu().numpy(), d["grad%d" % i], gmax) < gt, "grad %d" % i
+    for i, b in enumerate(m.buffers()):  # running_mean / running_var (num_batches_tracked is host-side)
+        ref = [d["buffer_after%d" % j] for j in range(len([f for f in d.files if f.startswith("buffer_after")])) if d["buffer_after%d" % j].dtype.kind == "f"][i]
+        assert np.allclose(b.cpu().numpy(), ref, rtol=10 * tol, atol=tol), "buffer %d" % i
+    if dt == "fp32":
+        opt = m.create_optimizer(float(d["lr"]))
+        opt.step(grad_scale=1.0 / int(d["batch_size"]))
+        assert abs(float(opt.last_grad_norm) - float(d["grad_norm"])) < 2e-4 * float(d["grad_norm"])
+        for i, p in enumerate(m.parameters()):
+            ref = d["param_after%d" % i]
+            assert rel(p.cpu().numpy(), ref, max(1e-3, float(np.abs(ref).max()))) < 1e-5, "param %d" % i
+        assert float(m.flat_grads.abs().max()) == 0.0  # zero_grad
+    # eval modes on the post-step fixture parameters
+    nbuf = [d[k] for k in sorted((f for f in d.files if f.startswith("buffer_after")), key=lambda s: int(s[12:])) if d[k].dtype.kind == "f"]
+    m.load_parameters([d["param_after%d" % i] for i in range(n)], nbuf)
+    m.eval()
+    with torch.no_grad():
+        assert rel(m.forward(x)[0][0].cpu().numpy(), d["eval_logits0"]) < tol
+        m.prepare_for_inference()
+        assert rel(m.forward(x)[0][0].cpu().numpy(), d["infer_logits0"]) < tol
+
+
+def test_default_arch_64_fp32_against_golden(golden_dir):
+    """default architecture (train.cpp:1054-1069) at 64^3, weights = ATen module init under manual_seed(0)"""
+    d = np.load(os.path.join(golden_dir, "default_arch_64.npz"))
+    n = int(d["n"])
+    torch.manual_seed(0)
+    ref = A.UNet3dRef(1, 6, A.default_feature(6))
+    pl2 = np.array([float(p.detach().double().norm()) for p in ref.parameters()])
+    if not np.allclose(pl2, d["param_l2"], rtol=1e-6):
+        pytest.fail("module init under manual_seed(0) differs from the fixture's (different torch build?)")
+    m = U.UNet3d(1, 6, A.default_feature(6), device=DEV, dtype="fp32")
+    m.load_parameters([p.detach().numpy() for p in ref.parameters()])
+    x, t = A.synthetic_sample(1, 6, (n, n, n), 1)
+    x, t = x.to(DEV), t.to(DEV)
+    plan = m.plan_for(x.shape[2:]); ws = m._workspace(plan)
+    outs = m._run_forward(plan, ws, x, 1)
+    for k in range(5):
+        a = outs[k][0].cpu().numpy()
+        a_s = a[:, ::4, ::4, ::4] if k == 0 else a
+        assert rel(a_s, d["logits%d" % k]) < 1e-4, "logits level %d" % k
+        assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - float(d["logits_l2_%d" % k])) < 1e-4 * float(d["logits_l2_%d" % k])
+    losses, gouts = m.loss(outs, t)
+    assert abs(float(losses[0]) - float(d["loss"])) < 1e-4 * float(d["loss"])
+    m._run_backward(plan, ws, gouts)
+    gl2 = np.array([float(g.double().norm()) for g in m.grads()])
+    big = d["grad_l2"] > 1e-3 * d["grad_l2"].max()   # conv biases before a norm have analytically zero gradient
+    assert np.allclose(gl2[big], d["grad_l2"][big], rtol=2e-3)
+    heads = np.stack([np.pad(g.flatten()[:16].cpu().numpy(), (0, max(0, 16 - g.numel()))) for g in m.grads()])
+    assert rel(heads[big], d["grad_head"][big]) < 2e-3
+
+
+@pytest.mark.parametrize("collapse", [0, 2])
+def test_fused_loss_vs_oracle(collapse):
+    """calc_losses (train.cpp:501-552): collapse_before, labels >= out_count masked, each cost switch"""
+    arch = "conv4\nconv4\nconv5,ks1"
+    m = U.UNet3d(1, 5, arch, device=DEV, dtype="fp32")
+    g = torch.Generator().manual_seed(3)
+    n = 12
+    logits = (3.0 * torch.randn((1, 5, n, n, n), generator=g)).to(DEV)
+    target = torch.randint(0, 7, (1, n, n, n), generator=g).to(DEV)
+    plan = m.plan_for((n, n, n))
+    for ce, dice, mse in ((1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)):
+        losses, gouts = m.loss([logits], target, bool(ce), bool(dice), bool(mse), collapse, plan=plan)
+        w = (ce, dice, mse) if (ce or dice or mse) else (1, 0, 0)
+        (oce, odice, omse), dl = O.calc_losses(logits[0].cpu().numpy(), target[0].cpu().numpy(), 5, collapse, w, True)
+        lo = losses.cpu().numpy()
+        assert np.allclose(lo[1:], [oce, odice, omse], rtol=2e-5, atol=2e-5)
+        assert abs(lo[0] - (w[0] * oce + w[1] * odice + w[2] * omse)) < 2e-5 * 3
+        assert rel(gouts[0][0].cpu().numpy(), dl) < 1e-4
+
+
+def test_autograd_bridge_matches_fused_path(golden_dir):
+    """torch losses can drive backward through forward()'s autograd edge (total_loss.backward(), train.cpp:706)"""
+    d, n = load_case(golden_dir, "mix_16")
+    m = U.UNet3d(int(d["cin"]), int(d["cout"]), str(d["arch"]), device=DEV, dtype="fp32")
+    m.load_parameters([d["param%d" % i] for i in range(n)])
+    x = torch.from_numpy(d["x"])[None].to(DEV); t = torch.from_numpy(d["target"])[None].to(DEV)
+    m.train()
+    outs = m.forward(x)
+    loss, _ = A.deep_supervision_loss(outs, t, int(d["cout"]))
+    loss.backward()
+    gmax = max(float(np.abs(d["grad%d" % i]).max()) for i in range(n))
+    for i, g in enumerate(m.grads()):
+        assert rel(g.cpu().numpy(), d["grad%d" % i], gmax) < 2e-4
+    # gradients accumulate across micro-steps (train.cpp:604-606,706)
+    before = m.flat_grads.clone()
+    m.forward_backward(x, t)
+    assert rel(m.flat_grads.cpu().numpy(), 2 * before.cpu().numpy()) < 1e-4
+
+
+def test_errors_surface_like_the_reference():
+    m = U.UNet3d(1, 2, "conv4\nconv4\nconv2,ks1", device=DEV, dtype="fp32")
+    with pytest.raises(U.UNetError):
+        m.forward(torch.zeros((1, 3, 8, 8, 8), device=DEV))
+    with pytest.raises(U.UNetError, match="invalid collapse_before"):
+        m.loss([torch.zeros((1, 2, 8, 8, 8), device=DEV)], torch.zeros((1, 8, 8, 8), dtype=torch.int64, device=DEV), collapse_before=2)
+
+
+@pytest.mark.parametrize("dt", ["bf16"])
+def test_full_size_128_properties(dt):
+    """BASELINE.json's size (default arch, 128^3): properties that need no CPU reference.
+    (1) bit-exact run-to-run determinism (no float atomics anywhere);
+    (2) instance norm makes the net invariant to the scale of a conv that feeds a norm;
+    (3) the deep-supervision gradient is consistent with a finite difference of the loss along a random direction."""
+    n = 128
+    m = U.UNet3d(1, 6, U.default_feature(6), device=DEV, dtype=dt, seed=0)
+    x, t = U.SyntheticVolumes(1, 6, (n, n, n), DEV)(0)
+    m.train()
+    l1 = m.forward_backward(x, t).clone(); g1 = m.flat_grads.clone()
+    m.flat_grads.zero_()
+    l2 = m.forward_backward(x, t).clone(); g2 = m.flat_grads.clone()
+    assert torch.equal(l1, l2) and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    with torch.no_grad():
+        base = m.forward(x)[0].clone()
+        m.parameters()[0].mul_(2.0); m.parameters()[1].mul_(2.0)   # encode0.0 conv feeds a norm
+        scaled = m.forward(x)[0]
+        assert rel(scaled.cpu().numpy(), base.cpu().numpy()) < 5e-2
+        m.parameters()[0].mul_(0.5); m.parameters()[1].mul_(0.5)
+    # directional derivative (fp32 master weights, bf16 activations: loose tolerance)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    dvec = torch.randn(m.flat_params.shape, generator=gen, device=DEV)
+    dvec *= (g1 != 0)
+    dvec /= dvec.norm()
+    eps = 2e-2
+    with torch.no_grad():
+        m.flat_params.add_(eps * dvec); lp = float(m.loss(m.forward(x), t, want_grad=False)[0][0])
+        m.flat_params.add_(-2 * eps * dvec); lm = float(m.loss(m.forward(x), t, want_grad=False)[0][0])
+        m.flat_params.add_(eps * dvec)
+    fd = (lp - lm) / (2 * eps)
+    an = float((g1 * dvec).sum())
+    assert abs(fd - an) < 0.25 * max(abs(an), 1e-3), (fd, an)

@@ -1,0 +1,94 @@
+"""CPU: the C-ABI library loads, exports every symbol include/unet_hip.h declares, and its host logic
+(DSL parser, graph lowering, parameter order, shapes, FLOP counts) matches the oracle restatements.
+No compute calls here (no GPU)."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+
+import unet_studio_amd as U
+from oracle import aten_ref as A
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "unet_hip.h")).read()
+    declared = set(re.findall(r"\b(unet_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"unet_plan"}
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(U.engine.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libunet_hip.so does not export " + name
+    assert declared == set(U.engine.EXPORTS)
+
+
+def test_plan_matches_reference_parameter_order_default_arch():
+    arch = A.default_feature(6)
+    p = U.Plan(arch, 1, 6, (128, 128, 128))
+    ref = A.UNet3dRef(1, 6, arch)
+    assert p.param_shapes == [tuple(q.shape) for q in ref.parameters()]
+    assert len(p.param_shapes) == 108 and sum(math.prod(s) for s in p.param_shapes) == 15025822
+    # weight decay mask, unet.cpp:254
+    names = [n for n, _ in ref.named_parameters()]
+    assert p.param_decay == [not ("bias" in n or q.dim() <= 1) for n, q in ref.named_parameters()], names
+    assert p.output_shapes == [(1, 6, 128 >> l, 128 >> l, 128 >> l) for l in range(5)]
+    # BASELINE.md §4 algorithmic work
+    assert abs(p.flops_fwd - 245.165e9) < 0.01e9 and abs(p.flops_bwd - 488.518e9) < 0.01e9
+    assert p.buffer_numel == []
+
+
+@pytest.mark.parametrize("arch,cin,cout", [
+    ("conv8,ks3,stride1+bnorm,relu+conv8,ks3,stride1+bnorm,relu\n"
+     "max_pool+conv16,ks3,stride1+bnorm,relu+conv16,ks3,stride1+bnorm,relu+conv_trans8,ks2,stride2\n"
+     "conv8,ks3,stride1+bnorm,relu+conv8,ks3,stride1+bnorm,relu+conv6,ks1,stride1", 1, 6),
+    ("conv8,ks3,stride1+norm,elu+conv8,ks3,stride1+norm,leaky_relu\n"
+     "conv16,ks3,stride2+norm,elu+conv16,ks3,stride1+norm,leaky_relu\n"
+     "max_pool+conv16,ks3,stride1+norm,relu+upsample\n"
+     "conv16,ks3,stride1+norm,leaky_relu+conv3,ks1,stride1+conv_trans8,ks2,stride2\n"
+     "conv8,ks3,stride1+norm,leaky_relu+conv3,ks1,stride1", 2, 3),
+    # head token with an activation and tokens that force materialisation (act after act, norm on a skip)
+    ("conv4,ks3,stride1,relu+norm,relu\nnorm+conv8,ks3,stride2,elu\nmax_pool+conv4,ks3,stride1+upsample\n"
+     "conv4,ks3,stride1+conv2,ks1,stride1,relu+conv_trans4\nconv4+conv2,ks1,stride1,relu", 1, 2),
+])
+def test_plan_shapes_match_oracles(arch, cin, cout):
+    try:
+        ref = A.UNet3dRef(cin, cout, arch)
+    except RuntimeError:
+        ref = None
+    o = O.OracleUNet(cin, cout, arch)
+    p = U.Plan(arch, cin, cout, (16, 16, 16), U.DTYPE_F32)
+    assert p.param_shapes == [q.shape for q in o.params]
+    if ref is not None:
+        assert p.param_shapes == [tuple(q.shape) for q in ref.parameters()]
+    assert len(p.buffer_numel) == len([b for b in o.buffers if b.dtype.kind == "f"])
+    assert p.workspace_bytes > 0 and "conv" in p.describe()
+
+
+def test_dsl_errors_match_reference_messages():
+    for arch, msg in (("conv8\nconv8", "invalid u-net structure"),
+                      ("conv8,ks5\nconv8\nconv8", "conv supports only ks1 stride1, ks3 stride1, and ks3 stride2"),
+                      ("conv8\nconv_trans8,ks3\nconv8", "conv_trans supports only ks2 stride2"),
+                      ("conv8\nfoo7\nconv8", "unknown layer: foo"),
+                      ("conv8\nconv8\nconv8\nconv8", "invalid u-net structure")):
+        with pytest.raises(U.UNetError, match=msg):
+            U.Plan(arch, 1, 2, (16, 16, 16))
+    with pytest.raises(U.UNetError, match="size mismatch"):  # skip and decoder input differ in size
+        U.Plan("conv4\nconv4,ks3,stride2\nconv4", 1, 2, (16, 16, 16))
+    with pytest.raises(U.UNetError, match="channel mismatch"):
+        U.Plan("conv4\nconv4\nconv2,ks1+conv2,ks1", 1, 2, (8, 8, 8))
+
+
+def test_crlf_and_blank_lines():
+    a = "conv4\r\n\r\nconv4\r\nconv2,ks1\r\n"
+    assert U.Plan(a, 1, 2, (8, 8, 8)).param_shapes == U.Plan("conv4\nconv4\nconv2,ks1", 1, 2, (8, 8, 8)).param_shapes
+
+
+def test_lowered_graph_fuses_norm_and_activation():
+    d = U.Plan(A.default_feature(6), 1, 6, (64, 64, 64)).describe()
+    assert "materialize" not in d          # every norm/act of the default architecture is read-fused
+    assert d.count("=> results[") == 5     # 5 heads write forward()'s results directly
+    assert "src[t2+norm+leaky_relu,t29]" in d  # cat(skip, x) is a dual-source read, never materialised

@@ -1,0 +1,599 @@
+// Plan + executor + C ABI (include/unet_hip.h).  The plan is immutable after creation; every call
+// works on caller-owned device memory (parameters, gradients, workspace) and a caller-owned stream,
+// so concurrent calls on one plan are safe when they use different workspaces (qc.cpp:273-297).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/unet_hip.h"
+#include "graph.hpp"
+#include "kernels.h"
+
+using namespace unet;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return 1; }
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        HIP_OK(hipGetDevice(&prev));
+        if (prev != dev) HIP_OK(hipSetDevice(dev));
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct unet_plan {
+    Graph g;
+    int dtype = 0, device = 0, impl = 0;
+    size_t elsize = 4;
+    // workspace layout (byte offsets)
+    std::vector<size_t> t_off, g_off;        // tensor storage / gradient storage (SIZE_MAX: none)
+    std::vector<size_t> n_stat, n_coef;      // per norm: 4C / 3C floats
+    std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
+    size_t partial_off = 0, partial_bytes = 0;
+    size_t ws_bytes = 0;
+    // loss scratch layout
+    size_t loss_bytes = 0;
+    // sgd
+    SgdSeg* segs_dev = nullptr;
+    int nseg = 0;
+    int64_t n_param_elems = 0;
+
+    ~unet_plan() {
+        if (segs_dev) (void)hipFree(segs_dev);
+    }
+
+    void layout() {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+        t_off.assign(g.tensors.size(), SIZE_MAX);
+        g_off.assign(g.tensors.size(), SIZE_MAX);
+        for (size_t i = 0; i < g.tensors.size(); ++i) {
+            t_off[i] = take((size_t)g.tensors[i].numel() * elsize);
+            if (g.tensors[i].needs_grad) g_off[i] = take((size_t)g.tensors[i].numel() * elsize);
+        }
+        n_stat.resize(g.norms.size()); n_coef.resize(g.norms.size());
+        size_t pmax = 0;
+        for (size_t i = 0; i < g.norms.size(); ++i) {
+            n_stat[i] = take(4 * (size_t)g.norms[i].C * 4);
+            n_coef[i] = take(3 * (size_t)g.norms[i].C * 4);
+            size_t pb = (size_t)stats_blocks(g.tensors[g.norms[i].tensor].voxels()) * g.norms[i].C * 2 * 4;
+            if (pb > pmax) pmax = pb;
+        }
+        partial_bytes = pmax ? pmax : 256;
+        partial_off = take(partial_bytes);
+        w_fwd.assign(g.ops.size(), SIZE_MAX); w_dgrad.assign(g.ops.size(), SIZE_MAX);
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
+            int k3 = op.kind == OP_CONV ? op.ks * op.ks * op.ks : 8;
+            w_fwd[i] = take((size_t)k3 * op.cin * round_up(op.cout, 8) * 4);
+            w_dgrad[i] = take((size_t)k3 * op.cout * round_up(op.cin, 8) * 4);
+        }
+        ws_bytes = off;
+    }
+};
+
+namespace {
+
+struct Exec {
+    const unet_plan& p;
+    char* ws;
+    hipStream_t s;
+    Exec(const unet_plan& plan, void* workspace, void* stream) : p(plan), ws((char*)workspace), s((hipStream_t)stream) {}
+
+    void* tptr(int t) const { return ws + p.t_off[t]; }
+    void* gptr(int t) const { return p.g_off[t] == SIZE_MAX ? nullptr : ws + p.g_off[t]; }
+    float* stat(int n) const { return (float*)(ws + p.n_stat[n]); }
+    float* coef(int n) const { return (float*)(ws + p.n_coef[n]); }
+    float* partial() const { return (float*)(ws + p.partial_off); }
+
+    SrcDesc src(int t) const {
+        const Tensor& T = p.g.tensors[t];
+        SrcDesc d;
+        d.ptr = tptr(t); d.C = T.C; d.act = T.act;
+        if (T.norm >= 0) { d.scale = stat(T.norm) + 2 * T.C; d.shift = stat(T.norm) + 3 * T.C; }
+        return d;
+    }
+    ConvGeom geom(const Op& op) const {
+        const Tensor& a = p.g.tensors[op.src[0]];
+        const Tensor& o = p.g.tensors[op.dst];
+        ConvGeom g;
+        g.Cin = op.cin; g.Cout = op.cout; g.D = a.D; g.H = a.H; g.W = a.W; g.Do = o.D; g.Ho = o.H; g.Wo = o.W;
+        g.ks = op.ks; g.stride = op.stride;
+        return g;
+    }
+
+    void forward(const float* const* params, float* const* buffers, const float* x, float* const* outs, int mode) {
+        const Graph& g = p.g;
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            switch (op.kind) {
+                case OP_PACK_INPUT:
+                    launch_pack_input(p.dtype, x, tptr(op.dst), g.in_c, g.tensors[op.dst].voxels(), s);
+                    break;
+                case OP_CONV:
+                case OP_CONVT: {
+                    if (op.out_level >= 0 && !(outs && outs[op.out_level])) break;  // result not wanted
+                    SrcDesc sd[2] = {src(op.src[0]), op.nsrc > 1 ? src(op.src[1]) : SrcDesc()};
+                    ConvGeom cg = geom(op);
+                    float* wf = (float*)(ws + p.w_fwd[i]);
+                    float* wd = (float*)(ws + p.w_dgrad[i]);
+                    if (op.kind == OP_CONV) {
+                        launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                        launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
+                                               op.out_level >= 0 ? outs[op.out_level] : nullptr, s);
+                    } else {
+                        launch_pack_convt_w(params[op.weight], wf, wd, op.cin, op.cout, s);
+                        launch_convt_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst), s);
+                    }
+                    break;
+                }
+                case OP_NORM: {
+                    const Norm& n = g.norms[op.norm];
+                    const Tensor& T = g.tensors[n.tensor];
+                    if (n.batch && mode == 0) {
+                        launch_norm_eval(n.C, params[n.gamma], params[n.beta], buffers[n.buffer], buffers[n.buffer + 1], n.eps,
+                                         stat(op.norm), s);
+                    } else {
+                        launch_stats_partial(p.dtype, tptr(n.tensor), n.C, T.voxels(), partial(), s);
+                        launch_norm_finalize(partial(), stats_blocks(T.voxels()), n.C, T.voxels(), params[n.gamma], params[n.beta],
+                                             n.eps, stat(op.norm), n.batch ? buffers[n.buffer] : nullptr,
+                                             n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, s);
+                    }
+                    break;
+                }
+                case OP_MATERIALIZE: {
+                    SrcDesc sd[2] = {src(op.src[0]), op.nsrc > 1 ? src(op.src[1]) : SrcDesc()};
+                    launch_materialize(p.dtype, sd, op.nsrc, tptr(op.dst), g.tensors[op.dst].voxels(), s);
+                    break;
+                }
+                case OP_MAXPOOL: {
+                    const Tensor& a = g.tensors[op.src[0]];
+                    launch_maxpool_fwd(p.dtype, src(op.src[0]), tptr(op.dst), a.D, a.H, a.W, s);
+                    break;
+                }
+                case OP_UPSAMPLE: {
+                    const Tensor& a = g.tensors[op.src[0]];
+                    launch_upsample_fwd(p.dtype, src(op.src[0]), tptr(op.dst), a.D, a.H, a.W, s);
+                    break;
+                }
+                case OP_EXPORT:
+                    if (outs && outs[op.out_level])
+                        launch_export(p.dtype, src(op.src[0]), outs[op.out_level], g.tensors[op.src[0]].voxels(), s);
+                    break;
+            }
+        }
+    }
+
+    // g[t] holds dL/d(view of t); turn it into dL/d(raw t) (and accumulate the norm's affine gradients)
+    void view_backward(int t, const float* const* params, float* const* gparams) {
+        const Tensor& T = p.g.tensors[t];
+        if (T.norm >= 0) {
+            const Norm& n = p.g.norms[T.norm];
+            launch_norm_bwd_partial(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), T.act, partial(), s);
+            launch_norm_bwd_finalize(partial(), stats_blocks(T.voxels()), T.C, T.voxels(), params[n.gamma], stat(T.norm), coef(T.norm),
+                                     gparams[n.gamma], gparams[n.beta], s);
+            launch_norm_bwd_apply(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), coef(T.norm), s);
+        } else if (T.act != ACT_NONE) {
+            launch_act_bwd(p.dtype, gptr(t), tptr(t), T.act, T.numel(), s);
+        }
+    }
+
+    void backward(const float* const* params, const float* const* grad_outs, float* const* gparams, float* grad_x) {
+        const Graph& g = p.g;
+        std::vector<char> init(g.tensors.size(), 0);
+        auto dst_of = [&](int t) {
+            DstGrad d;
+            d.C = g.tensors[t].C;
+            d.ptr = g.tensors[t].needs_grad ? gptr(t) : nullptr;
+            d.accumulate = init[t];
+            return d;
+        };
+        auto mark = [&](const Op& op) {
+            for (int k = 0; k < op.nsrc; ++k)
+                if (g.tensors[op.src[k]].needs_grad) init[op.src[k]] = 1;
+        };
+        for (int i = (int)g.ops.size() - 1; i >= 0; --i) {
+            const Op& op = g.ops[i];
+            if (op.kind == OP_NORM) continue;
+            if (op.kind == OP_EXPORT) {
+                if (grad_outs && grad_outs[op.out_level] && g.tensors[op.src[0]].needs_grad) {
+                    launch_export_bwd(p.dtype, grad_outs[op.out_level], dst_of(op.src[0]), g.tensors[op.src[0]].voxels(), s);
+                    mark(op);
+                }
+                continue;
+            }
+            int t = op.dst;
+            if ((op.kind == OP_CONV) && op.out_level >= 0) {
+                if (!(grad_outs && grad_outs[op.out_level])) continue;
+                launch_import_grad(p.dtype, grad_outs[op.out_level], gptr(t), g.tensors[t].C, g.tensors[t].voxels(), 0, s);
+                init[t] = 1;
+            }
+            if (!g.tensors[t].needs_grad || !init[t]) continue;
+            view_backward(t, params, gparams);
+            switch (op.kind) {
+                case OP_CONV:
+                case OP_CONVT: {
+                    SrcDesc sd[2] = {src(op.src[0]), op.nsrc > 1 ? src(op.src[1]) : SrcDesc()};
+                    DstGrad dg[2] = {dst_of(op.src[0]), op.nsrc > 1 ? dst_of(op.src[1]) : DstGrad()};
+                    ConvGeom cg = geom(op);
+                    const float* wd = (const float*)(ws + p.w_dgrad[i]);
+                    bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
+                    if (op.kind == OP_CONV) {
+                        launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
+                        if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
+                    } else {
+                        launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
+                        if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
+                    }
+                    if (any) mark(op);
+                    break;
+                }
+                case OP_MATERIALIZE: {
+                    DstGrad dg[2] = {dst_of(op.src[0]), op.nsrc > 1 ? dst_of(op.src[1]) : DstGrad()};
+                    if (dg[0].ptr || (op.nsrc > 1 && dg[1].ptr)) {
+                        // the materialized tensor is act(norm(src)): its gradient passes to the view of src unchanged
+                        launch_materialize_bwd(p.dtype, gptr(t), dg, op.nsrc, g.tensors[t].voxels(), s);
+                        mark(op);
+                    }
+                    break;
+                }
+                case OP_MAXPOOL: {
+                    const Tensor& a = g.tensors[op.src[0]];
+                    DstGrad d = dst_of(op.src[0]);
+                    if (d.ptr) { launch_maxpool_bwd(p.dtype, src(op.src[0]), gptr(t), d, a.D, a.H, a.W, s); mark(op); }
+                    break;
+                }
+                case OP_UPSAMPLE: {
+                    const Tensor& a = g.tensors[op.src[0]];
+                    DstGrad d = dst_of(op.src[0]);
+                    if (d.ptr) { launch_upsample_bwd(p.dtype, gptr(t), d, a.D, a.H, a.W, s); mark(op); }
+                    break;
+                }
+                case OP_PACK_INPUT:
+                    if (grad_x) launch_unpack_ncdhw(p.dtype, gptr(t), grad_x, g.in_c, g.tensors[t].voxels(), s);
+                    break;
+                default: break;
+            }
+        }
+    }
+};
+
+void check_launch() { HIP_OK(hipGetLastError()); }
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char* unet_last_error(void) { return g_err.c_str(); }
+
+int unet_init(int* n_devices) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { if (n_devices) *n_devices = 0; return fail(std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    if (n_devices) *n_devices = n;
+    return 0;
+}
+
+int unet_device_info(int device, char* name, size_t name_len, size_t* total_mem, int* compute_units, int* is_gfx950) {
+    hipDeviceProp_t pr;
+    hipError_t e = hipGetDeviceProperties(&pr, device);
+    if (e != hipSuccess) return fail(std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (name && name_len) { std::strncpy(name, pr.name, name_len - 1); name[name_len - 1] = 0; }
+    if (total_mem) *total_mem = pr.totalGlobalMem;
+    if (compute_units) *compute_units = pr.multiProcessorCount;
+    if (is_gfx950) *is_gfx950 = std::strncmp(pr.gcnArchName, "gfx950", 6) == 0;
+    return 0;
+}
+
+int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W, int dtype, int device, int impl, unet_plan** out) {
+    if (!arch || !out) return fail("unet_plan_create: null argument");
+    if (dtype != UNET_DTYPE_F32 && dtype != UNET_DTYPE_BF16) return fail("unet_plan_create: unknown dtype");
+    unet_plan* p = nullptr;
+    try {
+        p = new unet_plan();
+        p->g = Graph::build(arch, in_c, out_c, D, H, W);
+        // a norm's affine gradients need the gradient of the tensor it sits on, even on the network input
+        for (auto& n : p->g.norms) p->g.tensors[n.tensor].needs_grad = true;
+        p->dtype = dtype; p->device = device; p->impl = impl; p->elsize = dtype == UNET_DTYPE_F32 ? 4 : 2;
+        p->layout();
+        // loss scratch: target pyramid + partials + per-level results
+        {
+            size_t off = 0;
+            int oc = out_c;
+            for (size_t l = 0; l < p->g.outputs.size(); ++l) {
+                const auto& o = p->g.outputs[l];
+                int64_t S = (int64_t)(D >> l) * (H >> l) * (W >> l);
+                if (S <= 0) S = 1;
+                off = align_up(off + (size_t)S * 8);                               // target level l (l >= 1)
+                off = align_up(off + (size_t)(4 + 2 * oc) * 4);                    // level_out
+                (void)o;
+            }
+            off = align_up(off + (size_t)1024 * (3 + 2 * oc) * 4);                // partials
+            p->loss_bytes = off;
+        }
+        // sgd segment table
+        std::vector<SgdSeg> segs;
+        int64_t o = 0;
+        for (auto& pr : p->g.params) {
+            int64_t n = 1;
+            for (auto d : pr.shape) n *= d;
+            SgdSeg sg;
+            sg.offset = o; sg.count = n; sg.wd = pr.decay ? 1.f : 0.f;
+            segs.push_back(sg);
+            o += n;
+        }
+        p->n_param_elems = o;
+        p->nseg = (int)segs.size();
+        int nd = 0;
+        if (hipGetDeviceCount(&nd) == hipSuccess && nd > 0) {
+            DeviceGuard dg(device);
+            HIP_OK(hipMalloc((void**)&p->segs_dev, segs.size() * sizeof(SgdSeg)));
+            HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
+        }
+        *out = p;
+        return 0;
+    } catch (const std::exception& e) {
+        delete p;
+        return fail(e.what());
+    }
+}
+
+void unet_plan_destroy(unet_plan* p) { delete p; }
+
+int unet_plan_param_count(const unet_plan* p, int* n) { *n = (int)p->g.params.size(); return 0; }
+int unet_plan_param_shape(const unet_plan* p, int i, int64_t dims[5], int* ndim) {
+    if (i < 0 || i >= (int)p->g.params.size()) return fail("parameter index out of range");
+    const auto& s = p->g.params[i].shape;
+    *ndim = (int)s.size();
+    for (size_t k = 0; k < s.size(); ++k) dims[k] = s[k];
+    return 0;
+}
+int unet_plan_param_decay(const unet_plan* p, int i, int* decay) {
+    if (i < 0 || i >= (int)p->g.params.size()) return fail("parameter index out of range");
+    *decay = p->g.params[i].decay;
+    return 0;
+}
+int unet_plan_param_fan_in(const unet_plan* p, int i, int64_t* fan_in, int* is_norm_weight) {
+    if (i < 0 || i >= (int)p->g.params.size()) return fail("parameter index out of range");
+    *fan_in = p->g.params[i].fan_in; *is_norm_weight = p->g.params[i].norm_weight;
+    return 0;
+}
+int unet_plan_buffer_count(const unet_plan* p, int* n) { *n = (int)p->g.buffers.size(); return 0; }
+int unet_plan_buffer_shape(const unet_plan* p, int i, int64_t* numel) {
+    if (i < 0 || i >= (int)p->g.buffers.size()) return fail("buffer index out of range");
+    *numel = p->g.buffers[i];
+    return 0;
+}
+int unet_plan_output_count(const unet_plan* p, int* n) { *n = (int)p->g.outputs.size(); return 0; }
+int unet_plan_output_shape(const unet_plan* p, int l, int64_t dims[5]) {
+    if (l < 0 || l >= (int)p->g.outputs.size()) return fail("output level out of range");
+    const auto& o = p->g.outputs[l];
+    dims[0] = 1; dims[1] = o.C; dims[2] = o.D; dims[3] = o.H; dims[4] = o.W;
+    return 0;
+}
+int unet_plan_workspace_bytes(const unet_plan* p, size_t* bytes) { *bytes = p->ws_bytes; return 0; }
+int unet_plan_flops(const unet_plan* p, double* fwd, double* bwd) { *fwd = p->g.flops_fwd; *bwd = p->g.flops_bwd; return 0; }
+size_t unet_plan_describe(const unet_plan* p, char* buf, size_t len) {
+    std::string d = p->g.describe();
+    if (buf && len) { std::strncpy(buf, d.c_str(), len - 1); buf[len - 1] = 0; }
+    return d.size() + 1;
+}
+
+int unet_forward(const unet_plan* p, const float* const* params, float* const* buffers, const float* x, float* const* outs,
+                 void* workspace, int mode, void* stream) {
+    try {
+        if (!p || !params || !x || !workspace) throw std::runtime_error("unet_forward: null argument");
+        if (!p->g.buffers.empty() && !buffers) throw std::runtime_error("unet_forward: architecture has bnorm layers but buffers is null");
+        DeviceGuard dg(p->device);
+        Exec ex(*p, workspace, stream);
+        ex.forward(params, buffers, x, outs, mode);
+        check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int unet_backward(const unet_plan* p, const float* const* params, const float* const* grad_outs, float* const* grad_params,
+                  float* grad_x, void* workspace, void* stream) {
+    try {
+        if (!p || !params || !grad_params || !workspace) throw std::runtime_error("unet_backward: null argument");
+        DeviceGuard dg(p->device);
+        Exec ex(*p, workspace, stream);
+        ex.backward(params, grad_outs, grad_params, grad_x);
+        check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int unet_loss_scratch_bytes(const unet_plan* p, size_t* bytes) { *bytes = p->loss_bytes; return 0; }
+
+int unet_loss(const unet_plan* p, const float* const* outs, const int64_t* target, int cost_mask, int collapse_before,
+              float* const* grad_outs, float* losses_out, void* scratch, void* stream) {
+    try {
+        if (!p || !outs || !target || !losses_out || !scratch) throw std::runtime_error("unet_loss: null argument");
+        const Graph& g = p->g;
+        int C = g.out_c;
+        if (collapse_before < 0 || collapse_before >= C) throw std::runtime_error("invalid collapse_before");
+        int oc = collapse_before ? C - collapse_before + 1 : C;
+        DeviceGuard dg(p->device);
+        hipStream_t s = (hipStream_t)stream;
+        size_t nl = g.outputs.size();
+        float wsum = 0.f;
+        for (size_t k = 0; k < nl; ++k) wsum += 1.0f / (float)(1 << k);
+        float inv = 1.0f / wsum;
+        HIP_OK(hipMemsetAsync(losses_out, 0, 4 * sizeof(float), s));
+        char* sc = (char*)scratch;
+        size_t off = 0;
+        std::vector<int64_t*> tgt(nl);
+        std::vector<float*> lvl(nl);
+        for (size_t l = 0; l < nl; ++l) {
+            int64_t S = (int64_t)(g.D >> l) * (g.H >> l) * (g.W >> l);
+            if (S <= 0) S = 1;
+            tgt[l] = (int64_t*)(sc + off); off = align_up(off + (size_t)S * 8);
+            lvl[l] = (float*)(sc + off); off = align_up(off + (size_t)(4 + 2 * C) * 4);
+        }
+        float* partial = (float*)(sc + off);
+        const int64_t* cur = target;
+        int D = g.D, H = g.H, W = g.W;
+        for (size_t k = 0; k < nl; ++k) {
+            if (k > 0) {
+                if ((D >> 1) <= 0 || (H >> 1) <= 0 || (W >> 1) <= 0) throw std::runtime_error("deep supervision target size became zero");
+                launch_target_half(cur, tgt[k], D, H, W, s);
+                cur = tgt[k]; D >>= 1; H >>= 1; W >>= 1;
+            }
+            const auto& o = g.outputs[k];
+            if (o.C == 0 || !outs[k]) throw std::runtime_error("undefined deep supervision output at level " + std::to_string(k));
+            if (o.C != C)
+                throw std::runtime_error("output channel mismatch at level " + std::to_string(k) + ": tensor has " + std::to_string(o.C) +
+                                         ", out_count is " + std::to_string(C));
+            if (o.D != D || o.H != H || o.W != W) throw std::runtime_error("deep supervision output/target size mismatch at level " + std::to_string(k));
+            int64_t S = (int64_t)D * H * W;
+            float w = (1.0f / (float)(1 << k)) * inv;
+            launch_loss_partial(outs[k], cur, C, S, collapse_before, partial, s);
+            launch_loss_finalize(partial, loss_blocks(S), oc, w, cost_mask, lvl[k], losses_out, k == 0, s);
+            if (grad_outs && grad_outs[k]) launch_loss_grad(outs[k], cur, C, S, collapse_before, lvl[k], w, cost_mask, grad_outs[k], s);
+        }
+        check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, float lr, float momentum, int nesterov, float wd,
+                  float clip_norm, float grad_scale, float* norm_out, void* scratch, void* stream) {
+    try {
+        if (!p || !params || !grads || !mom || !scratch) throw std::runtime_error("unet_sgd_step: null argument");
+        if (!p->segs_dev) throw std::runtime_error("unet_sgd_step: plan was created without a device");
+        DeviceGuard dg(p->device);
+        hipStream_t s = (hipStream_t)stream;
+        const int nblk = 256;
+        float* partial = (float*)scratch;
+        launch_sumsq_partial(grads, p->n_param_elems, grad_scale, partial, nblk, s);
+        launch_sgd(params, grads, mom, p->n_param_elems, p->segs_dev, p->nseg, partial, nblk, lr, momentum, nesterov, wd, clip_norm,
+                   grad_scale, norm_out, s);
+        check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+// ---- single-op surface ----
+int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes) {
+    (void)D; (void)H; (void)W;
+    *bytes = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096;
+    return 0;
+}
+
+static ConvGeom op_geom(int cin, int cout, int D, int H, int W, int ks, int stride, bool transposed) {
+    ConvGeom g;
+    g.Cin = cin; g.Cout = cout; g.D = D; g.H = H; g.W = W; g.ks = ks; g.stride = stride;
+    if (transposed) { g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W; }
+    else {
+        int pad = (ks - 1) / 2;
+        g.Do = (D + 2 * pad - ks) / stride + 1; g.Ho = (H + 2 * pad - ks) / stride + 1; g.Wo = (W + 2 * pad - ks) / stride + 1;
+    }
+    return g;
+}
+static void op_pack(const float* w, int cin, int cout, int k3, bool transposed, void* scratch, float** wf, float** wd, hipStream_t s) {
+    size_t half = align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
+    *wf = (float*)scratch; *wd = (float*)((char*)scratch + half);
+    if (transposed) launch_pack_convt_w(w, *wf, *wd, cin, cout, s);
+    else launch_pack_conv_w(w, *wf, *wd, cin, cout, k3, s);
+}
+#define OP_TRY(...) try { __VA_ARGS__; check_launch(); return 0; } catch (const std::exception& e) { return fail(e.what()); }
+
+int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D, int H,
+                       int W, int ks, int stride, void* scratch, void* stream) {
+    OP_TRY({
+        (void)impl;
+        hipStream_t s = (hipStream_t)stream;
+        ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
+        float *wf, *wd;
+        op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
+        SrcDesc sd; sd.ptr = x; sd.C = cin;
+        launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+    })
+}
+int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H, int W,
+                            int ks, int stride, void* scratch, void* stream) {
+    OP_TRY({
+        (void)impl;
+        hipStream_t s = (hipStream_t)stream;
+        ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
+        float *wf, *wd;
+        op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
+        DstGrad d; d.ptr = dx; d.C = cin; d.accumulate = 0;
+        launch_conv_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
+    })
+}
+int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout, int D,
+                              int H, int W, int ks, int stride, void* scratch, void* stream) {
+    OP_TRY({
+        (void)impl; (void)scratch;
+        ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
+        SrcDesc sd; sd.ptr = x; sd.C = cin;
+        launch_conv_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, (hipStream_t)stream);
+    })
+}
+int unet_op_convt_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D, int H,
+                      int W, void* scratch, void* stream) {
+    OP_TRY({
+        (void)impl;
+        hipStream_t s = (hipStream_t)stream;
+        ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
+        float *wf, *wd;
+        op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
+        SrcDesc sd; sd.ptr = x; sd.C = cin;
+        launch_convt_fwd_direct(dtype, g, &sd, 1, wf, b, y, s);
+    })
+}
+int unet_op_convt_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H, int W,
+                           void* scratch, void* stream) {
+    OP_TRY({
+        (void)impl;
+        hipStream_t s = (hipStream_t)stream;
+        ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
+        float *wf, *wd;
+        op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
+        DstGrad d; d.ptr = dx; d.C = cin; d.accumulate = 0;
+        launch_convt_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
+    })
+}
+int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout, int D, int H,
+                             int W, void* scratch, void* stream) {
+    OP_TRY({
+        (void)impl; (void)scratch;
+        ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
+        SrcDesc sd; sd.ptr = x; sd.C = cin;
+        launch_convt_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, (hipStream_t)stream);
+    })
+}
+int unet_op_pack_ndhwc(int dtype, const float* x, void* y, int C, int64_t S, void* stream) {
+    OP_TRY({ launch_pack_input(dtype, x, y, C, S, (hipStream_t)stream); })
+}
+int unet_op_unpack_ncdhw(int dtype, const void* x, float* y, int C, int64_t S, void* stream) {
+    OP_TRY({ launch_unpack_ncdhw(dtype, x, y, C, S, (hipStream_t)stream); })
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Launchers of the HIP kernels (gfx950).  Every function enqueues on `stream` and returns; errors are
+// reported through hipGetLastError() by the caller.  dtype: 0 fp32, 1 bf16 element type of the
+// channels-last activation/gradient tensors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace unet {
+
+// A tensor as a consumer sees it: act(x * scale[c] + shift[c]) (scale == nullptr: identity affine).
+struct SrcDesc {
+    const void* ptr = nullptr;
+    int C = 0;
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    int act = 0;
+};
+// Gradient destination of one source: written (accumulate == 0) or added to (accumulate == 1).
+struct DstGrad {
+    void* ptr = nullptr;  // nullptr: this source needs no gradient
+    int C = 0;
+    int accumulate = 0;
+};
+
+struct ConvGeom {
+    int Cin = 0, Cout = 0;
+    int D = 0, H = 0, W = 0;     // input volume
+    int Do = 0, Ho = 0, Wo = 0;  // output volume
+    int ks = 3, stride = 1;
+};
+
+__host__ __device__ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---- weight repacking (fp32 torch layout -> kernel layouts), once per parameter update ----
+// conv  [Cout][Cin][k3]  -> fwd  [k3][Cin][CoutP]   and dgrad [k3][Cout][CinP]   (P = padded to 8)
+void launch_pack_conv_w(const float* w, float* w_fwd, float* w_dgrad, int Cin, int Cout, int k3, hipStream_t s);
+// convT [Cin][Cout][8]   -> fwd  [8][Cin][CoutP]    and dgrad [8][Cout][CinP]
+void launch_pack_convt_w(const float* w, float* w_fwd, float* w_dgrad, int Cin, int Cout, hipStream_t s);
+
+// ---- layout ----
+void launch_pack_input(int dtype, const float* x_ncdhw, void* y, int C, int64_t S, hipStream_t s);
+void launch_export(int dtype, SrcDesc src, float* y_ncdhw, int64_t S, hipStream_t s);                // view -> fp32 NCDHW
+void launch_import_grad(int dtype, const float* g_ncdhw, void* g, int C, int64_t S, int accumulate, hipStream_t s);
+
+// ---- direct (non-MFMA) conv family ----
+// out: channels-last element type, or (out_ncdhw != nullptr) fp32 NCDHW external output
+void launch_conv_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias,
+                            void* out, float* out_ncdhw, hipStream_t s);
+void launch_conv_dgrad_direct(int dtype, const ConvGeom& g, const void* dy, const float* w_dgrad, const DstGrad* dst, int ndst,
+                              hipStream_t s);
+// dw/db in torch layout, accumulated (+=)
+void launch_conv_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
+                              hipStream_t s);
+void launch_convt_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias,
+                             void* out, hipStream_t s);
+void launch_convt_dgrad_direct(int dtype, const ConvGeom& g, const void* dy, const float* w_dgrad, const DstGrad* dst, int ndst,
+                               hipStream_t s);
+void launch_convt_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
+                               hipStream_t s);
+
+// ---- normalisation ----
+// number of partial blocks the statistics kernels use for S voxels (plan-time constant)
+int stats_blocks(int64_t S);
+// per-block partial {sum, sumsq} of a raw tensor: partial[blk][c][2]
+void launch_stats_partial(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s);
+// partials -> stat[0..C) mean, [C..2C) rstd, [2C..3C) scale = gamma*rstd, [3C..4C) shift = beta - mean*scale;
+// running stats (bnorm, may be nullptr): rm = (1-m)*rm + m*mean, rv = (1-m)*rv + m*unbiased var
+void launch_norm_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
+                          float* stat, float* running_mean, float* running_var, double momentum, hipStream_t s);
+// eval-mode bnorm: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (mean := rm, rstd := 1/sqrt(rv+eps))
+void launch_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat,
+                      hipStream_t s);
+
+// ---- view backward: g holds dL/d(act(norm(u))) on entry ----
+// no norm: g *= act'(u)
+void launch_act_bwd(int dtype, void* g, const void* u, int act, int64_t n, hipStream_t s);
+// with norm: pass 1: g <- dv = g*act'(v), partial[blk][c] = {sum dv, sum dv*xhat}
+void launch_norm_bwd_partial(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, int act, float* partial,
+                             hipStream_t s);
+// pass 2: coef[0..C) = gamma*rstd, [C..2C) = mean(dv), [2C..3C) = mean(dv*xhat); dgamma += sum dv*xhat, dbeta += sum dv
+void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat, float* coef,
+                              float* dgamma, float* dbeta, hipStream_t s);
+// pass 3: g <- du = coef0 * (dv - m1 - xhat*m2)
+void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, hipStream_t s);
+
+// ---- pooling / resampling / copies ----
+void launch_maxpool_fwd(int dtype, SrcDesc src, void* out, int D, int H, int W, hipStream_t s);
+void launch_maxpool_bwd(int dtype, SrcDesc src, const void* gout, DstGrad dst, int D, int H, int W, hipStream_t s);
+void launch_upsample_fwd(int dtype, SrcDesc src, void* out, int D, int H, int W, hipStream_t s);
+void launch_upsample_bwd(int dtype, const void* gout, DstGrad dst, int D, int H, int W, hipStream_t s);
+void launch_materialize(int dtype, const SrcDesc* src, int nsrc, void* out, int64_t S, hipStream_t s);
+void launch_materialize_bwd(int dtype, const void* gout, const DstGrad* dst, int ndst, int64_t S, hipStream_t s);
+void launch_export_bwd(int dtype, const float* g_ncdhw, DstGrad dst, int64_t S, hipStream_t s);
+void launch_unpack_ncdhw(int dtype, const void* g, float* out_ncdhw, int C, int64_t S, hipStream_t s);
+
+// ---- losses (train.cpp:501-552, 634-706) ----
+void launch_target_half(const int64_t* t, int64_t* o, int D, int H, int W, hipStream_t s);
+int loss_blocks(int64_t S);
+// pass 1: per-block partials [blk][3 + 2*oc]: {ce, mse, nvalid, inter[oc], card[oc]}
+void launch_loss_partial(const float* logits, const int64_t* target, int C, int64_t S, int collapse, float* partial, hipStream_t s);
+// pass 2: level_out[0..2] = ce, dice, mse; level_out[3 ..] = n, inter[oc], card[oc]; totals[0] += weight*(selected), totals[1..3] = stats when set_stats
+void launch_loss_finalize(const float* partial, int nblk, int oc, float level_weight, int cost_mask, float* level_out, float* totals,
+                          int set_stats, hipStream_t s);
+// pass 3: dlogits = level_weight * d(selected losses)/dlogits
+void launch_loss_grad(const float* logits, const int64_t* target, int C, int64_t S, int collapse, const float* level_out,
+                      float level_weight, int cost_mask, float* dlogits, hipStream_t s);
+
+// ---- step epilogue ----
+struct SgdSeg { int64_t offset, count; float wd; };  // wd: 1 when weight decay applies to the tensor, else 0
+void launch_sumsq_partial(const float* g, int64_t n, float scale, float* partial, int nblk, hipStream_t s);
+void launch_sgd(float* p, float* g, float* m, int64_t n, const SgdSeg* segs_dev, int nseg, const float* partial, int nblk,
+                float lr, float momentum, int nesterov, float weight_decay, float clip_norm, float grad_scale, float* norm_out,
+                hipStream_t s);
+
+// ---- MFMA implicit-GEMM family (kernels_mfma.hip), bf16 only ----
+bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t mfma_conv_w_bytes(const ConvGeom& g);
+void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
+void launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
+                          float* stats_partial, hipStream_t s);
+
+}  // namespace unet

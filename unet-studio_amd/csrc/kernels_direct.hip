@@ -1,0 +1,390 @@
+// Direct (non-MFMA) conv family: correct for every channel count and both element types; used for the
+// fp32 parity configuration, for layers the MFMA kernels do not cover (Cin = 1, 6-channel heads, odd
+// channel counts) and as the on-GPU cross-check of the MFMA kernels.  fp32 accumulation throughout.
+// Semantics: Conv3d ks{1,3} stride{1,2} pad (ks-1)/2 (unet.cpp:59-72), ConvTranspose3d ks2 stride2
+// (unet.cpp:46-57), and their autograd gradients (train.cpp:706).
+#include "device_util.h"
+
+namespace unet {
+
+// ------------------------------------------------------------------------------------------------
+// weight repacking
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_conv_w(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd, int Cin, int Cout,
+                              int k3, int CoutP, int CinP) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t nf = (int64_t)k3 * Cin * CoutP, nd = (int64_t)k3 * Cout * CinP;
+    if (i < nf) {
+        int co = (int)(i % CoutP); int64_t r = i / CoutP;
+        int ci = (int)(r % Cin); int t = (int)(r / Cin);
+        wf[i] = co < Cout ? w[((int64_t)co * Cin + ci) * k3 + t] : 0.f;
+    }
+    if (i < nd) {
+        int ci = (int)(i % CinP); int64_t r = i / CinP;
+        int co = (int)(r % Cout); int t = (int)(r / Cout);
+        wd[i] = ci < Cin ? w[((int64_t)co * Cin + ci) * k3 + t] : 0.f;
+    }
+}
+__global__ void k_pack_convt_w(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd, int Cin, int Cout,
+                               int CoutP, int CinP) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t nf = (int64_t)8 * Cin * CoutP, nd = (int64_t)8 * Cout * CinP;
+    if (i < nf) {
+        int co = (int)(i % CoutP); int64_t r = i / CoutP;
+        int ci = (int)(r % Cin); int t = (int)(r / Cin);
+        wf[i] = co < Cout ? w[((int64_t)ci * Cout + co) * 8 + t] : 0.f;
+    }
+    if (i < nd) {
+        int ci = (int)(i % CinP); int64_t r = i / CinP;
+        int co = (int)(r % Cout); int t = (int)(r / Cout);
+        wd[i] = ci < Cin ? w[((int64_t)ci * Cout + co) * 8 + t] : 0.f;
+    }
+}
+void launch_pack_conv_w(const float* w, float* wf, float* wd, int Cin, int Cout, int k3, hipStream_t s) {
+    int CoutP = round_up(Cout, 8), CinP = round_up(Cin, 8);
+    int64_t na = (int64_t)k3 * Cin * CoutP, nb = (int64_t)k3 * Cout * CinP;
+    int64_t n = na > nb ? na : nb;
+    k_pack_conv_w<<<cdiv64(n, 256), 256, 0, s>>>(w, wf, wd, Cin, Cout, k3, CoutP, CinP);
+}
+void launch_pack_convt_w(const float* w, float* wf, float* wd, int Cin, int Cout, hipStream_t s) {
+    int CoutP = round_up(Cout, 8), CinP = round_up(Cin, 8);
+    int64_t a = (int64_t)8 * Cin * CoutP, b = (int64_t)8 * Cout * CinP;
+    k_pack_convt_w<<<cdiv64(a > b ? a : b, 256), 256, 0, s>>>(w, wf, wd, Cin, Cout, CoutP, CinP);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv forward: one thread = one output voxel x 8 output channels
+// ------------------------------------------------------------------------------------------------
+struct ConvFwdArgs {
+    ConvGeom g;
+    SrcDesc src[2];
+    int nsrc;
+    const float* w;   // [k3][Cin][CoutP]
+    const float* bias;
+    void* out;
+    float* out_ncdhw;
+};
+
+template <typename T> __global__ void __launch_bounds__(256) k_conv_fwd_direct(ConvFwdArgs a) {
+    const ConvGeom& g = a.g;
+    int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+    int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= So) return;
+    int co0 = blockIdx.y * 8, CoutP = round_up(g.Cout, 8);
+    int x = (int)(v % g.Wo); int64_t r = v / g.Wo;
+    int y = (int)(r % g.Ho); int z = (int)(r / g.Ho);
+    int pad = (g.ks - 1) / 2;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (a.bias && co0 + j < g.Cout) ? a.bias[co0 + j] : 0.f;
+    for (int kz = 0; kz < g.ks; ++kz) {
+        int iz = z * g.stride + kz - pad;
+        if (iz < 0 || iz >= g.D) continue;
+        for (int ky = 0; ky < g.ks; ++ky) {
+            int iy = y * g.stride + ky - pad;
+            if (iy < 0 || iy >= g.H) continue;
+            for (int kx = 0; kx < g.ks; ++kx) {
+                int ix = x * g.stride + kx - pad;
+                if (ix < 0 || ix >= g.W) continue;
+                int64_t vin = ((int64_t)iz * g.H + iy) * g.W + ix;
+                int tap = (kz * g.ks + ky) * g.ks + kx;
+                int cb = 0;
+                for (int s = 0; s < a.nsrc; ++s) {
+                    const SrcDesc& sd = a.src[s];
+                    for (int ci = 0; ci < sd.C; ++ci) {
+                        float xv = view_ld<T>(sd, vin, ci);
+                        const float* wr = a.w + ((int64_t)tap * g.Cin + cb + ci) * CoutP + co0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+                    }
+                    cb += sd.C;
+                }
+            }
+        }
+    }
+    if (a.out_ncdhw) {
+        for (int j = 0; j < 8; ++j)
+            if (co0 + j < g.Cout) a.out_ncdhw[(int64_t)(co0 + j) * So + v] = acc[j];
+    } else {
+        T* o = (T*)a.out;
+        for (int j = 0; j < 8; ++j)
+            if (co0 + j < g.Cout) st<T>(o, v * g.Cout + co0 + j, acc[j]);
+    }
+}
+
+void launch_conv_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w, const float* bias,
+                            void* out, float* out_ncdhw, hipStream_t s) {
+    ConvFwdArgs a;
+    a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
+    a.w = w; a.bias = bias; a.out = out; a.out_ncdhw = out_ncdhw;
+    int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+    dim3 grid(cdiv64(So, 256), (g.Cout + 7) / 8);
+    UNET_DISPATCH(dtype, (k_conv_fwd_direct<T><<<grid, 256, 0, s>>>(a)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv dgrad: one thread = one input voxel x 8 input channels
+// ------------------------------------------------------------------------------------------------
+struct ConvDgradArgs {
+    ConvGeom g;
+    const void* dy;
+    const float* w;  // [k3][Cout][CinP]
+    DstGrad dst[2];
+    int ndst;
+};
+
+template <typename T> __device__ __forceinline__ void write_grad(const DstGrad* dst, int ndst, int64_t v, int c, float val) {
+    int cb = 0;
+    for (int s = 0; s < ndst; ++s) {
+        if (c < cb + dst[s].C) {
+            if (dst[s].ptr) {
+                T* p = (T*)dst[s].ptr;
+                int64_t i = v * dst[s].C + (c - cb);
+                if (dst[s].accumulate) val += ld<T>(p, i);
+                st<T>(p, i, val);
+            }
+            return;
+        }
+        cb += dst[s].C;
+    }
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_conv_dgrad_direct(ConvDgradArgs a) {
+    const ConvGeom& g = a.g;
+    int64_t S = (int64_t)g.D * g.H * g.W;
+    int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= S) return;
+    int ci0 = blockIdx.y * 8, CinP = round_up(g.Cin, 8);
+    int ix = (int)(v % g.W); int64_t r = v / g.W;
+    int iy = (int)(r % g.H); int iz = (int)(r / g.H);
+    int pad = (g.ks - 1) / 2;
+    const T* dy = (const T*)a.dy;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int kz = 0; kz < g.ks; ++kz) {
+        int tz = iz + pad - kz;
+        if (tz < 0 || (tz % g.stride) != 0) continue;
+        int z = tz / g.stride;
+        if (z >= g.Do) continue;
+        for (int ky = 0; ky < g.ks; ++ky) {
+            int ty = iy + pad - ky;
+            if (ty < 0 || (ty % g.stride) != 0) continue;
+            int y = ty / g.stride;
+            if (y >= g.Ho) continue;
+            for (int kx = 0; kx < g.ks; ++kx) {
+                int tx = ix + pad - kx;
+                if (tx < 0 || (tx % g.stride) != 0) continue;
+                int x = tx / g.stride;
+                if (x >= g.Wo) continue;
+                int64_t vo = ((int64_t)z * g.Ho + y) * g.Wo + x;
+                int tap = (kz * g.ks + ky) * g.ks + kx;
+                for (int co = 0; co < g.Cout; ++co) {
+                    float d = ld<T>(dy, vo * g.Cout + co);
+                    const float* wr = a.w + ((int64_t)tap * g.Cout + co) * CinP + ci0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, wr[j], acc[j]);
+                }
+            }
+        }
+    }
+    for (int j = 0; j < 8; ++j)
+        if (ci0 + j < g.Cin) write_grad<T>(a.dst, a.ndst, v, ci0 + j, acc[j]);
+}
+
+void launch_conv_dgrad_direct(int dtype, const ConvGeom& g, const void* dy, const float* w, const DstGrad* dst, int ndst,
+                              hipStream_t s) {
+    ConvDgradArgs a;
+    a.g = g; a.dy = dy; a.w = w; a.ndst = ndst; a.dst[0] = dst[0]; if (ndst > 1) a.dst[1] = dst[1];
+    int64_t S = (int64_t)g.D * g.H * g.W;
+    dim3 grid(cdiv64(S, 256), (g.Cin + 7) / 8);
+    UNET_DISPATCH(dtype, (k_conv_dgrad_direct<T><<<grid, 256, 0, s>>>(a)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad (conv and conv_trans): one block = one (tap, ci); threads = output channels x row lanes
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    ConvGeom g;
+    SrcDesc src[2];
+    int nsrc;
+    const void* dy;
+    float* dw;
+    int transposed;  // 0 conv, 1 conv_trans (ks2 stride2)
+    int CW;          // threads along cout (power of two <= 256)
+};
+
+template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(WgradArgs a) {
+    const ConvGeom& g = a.g;
+    __shared__ double red[256];
+    int k3 = a.transposed ? 8 : g.ks * g.ks * g.ks;
+    int tap = blockIdx.x % k3, ci = blockIdx.x / k3;
+    int CW = a.CW, NV = 256 / CW;
+    int co = blockIdx.y * CW + (threadIdx.x % CW), lane = threadIdx.x / CW;
+    // which source holds input channel ci
+    SrcDesc sd = a.src[0];
+    int cl = ci;
+    if (a.nsrc > 1 && ci >= a.src[0].C) { sd = a.src[1]; cl = ci - a.src[0].C; }
+    const T* dy = (const T*)a.dy;
+    double acc = 0.0;
+    if (co < g.Cout) {
+        if (!a.transposed) {
+            int pad = (g.ks - 1) / 2;
+            int kz = tap / (g.ks * g.ks), ky = (tap / g.ks) % g.ks, kx = tap % g.ks;
+            for (int row = lane; row < g.Do * g.Ho; row += NV) {
+                int z = row / g.Ho, y = row % g.Ho;
+                int iz = z * g.stride + kz - pad, iy = y * g.stride + ky - pad;
+                if (iz < 0 || iz >= g.D || iy < 0 || iy >= g.H) continue;
+                int64_t ibase = ((int64_t)iz * g.H + iy) * g.W, obase = (int64_t)row * g.Wo;
+                float racc = 0.f;
+                for (int x = 0; x < g.Wo; ++x) {
+                    int ix = x * g.stride + kx - pad;
+                    if (ix < 0 || ix >= g.W) continue;
+                    racc = fmaf(view_ld<T>(sd, ibase + ix, cl), ld<T>(dy, (obase + x) * g.Cout + co), racc);
+                }
+                acc += (double)racc;
+            }
+        } else {
+            int tz = tap >> 2, ty = (tap >> 1) & 1, tx = tap & 1;
+            for (int row = lane; row < g.D * g.H; row += NV) {
+                int z = row / g.H, y = row % g.H;
+                int64_t ibase = (int64_t)row * g.W, obase = ((int64_t)(2 * z + tz) * g.Ho + (2 * y + ty)) * g.Wo + tx;
+                float racc = 0.f;
+                for (int x = 0; x < g.W; ++x)
+                    racc = fmaf(view_ld<T>(sd, ibase + x, cl), ld<T>(dy, (obase + 2 * x) * g.Cout + co), racc);
+                acc += (double)racc;
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane == 0 && co < g.Cout) {
+        double s = 0.0;
+        for (int l = 0; l < NV; ++l) s += red[l * CW + (threadIdx.x % CW)];
+        int64_t idx = a.transposed ? ((int64_t)ci * g.Cout + co) * 8 + tap : ((int64_t)co * g.Cin + ci) * k3 + tap;
+        a.dw[idx] += (float)s;
+    }
+}
+
+// bias grad: db[c] += sum over voxels of dy[v][c]; one block per channel
+template <typename T> __global__ void __launch_bounds__(256) k_bias_grad(const T* __restrict__ dy, int C, int64_t S, float* db) {
+    __shared__ double red[256];
+    int c = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t v0 = threadIdx.x; v0 < S; v0 += 256 * 64) {
+        float r = 0.f;
+        for (int k = 0; k < 64; ++k) {
+            int64_t v = v0 + (int64_t)k * 256;
+            if (v < S) r += ld<T>(dy, v * C + c);
+        }
+        acc += (double)r;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] += (float)red[0];
+}
+
+static void launch_wgrad_common(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
+                                int transposed, hipStream_t s) {
+    WgradArgs a;
+    a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
+    a.dy = dy; a.dw = dw; a.transposed = transposed;
+    int CW = 1;
+    while (CW < g.Cout && CW < 256) CW <<= 1;
+    a.CW = CW;
+    int k3 = transposed ? 8 : g.ks * g.ks * g.ks;
+    dim3 grid((unsigned)(k3 * g.Cin), (unsigned)((g.Cout + CW - 1) / CW));
+    UNET_DISPATCH(dtype, (k_wgrad_direct<T><<<grid, 256, 0, s>>>(a)));
+    if (db) {
+        int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+        UNET_DISPATCH(dtype, (k_bias_grad<T><<<g.Cout, 256, 0, s>>>((const T*)dy, g.Cout, So, db)));
+    }
+}
+void launch_conv_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
+                              hipStream_t s) {
+    launch_wgrad_common(dtype, g, src, nsrc, dy, dw, db, 0, s);
+}
+void launch_convt_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
+                               hipStream_t s) {
+    launch_wgrad_common(dtype, g, src, nsrc, dy, dw, db, 1, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_trans ks2 stride2 forward / dgrad
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void __launch_bounds__(256) k_convt_fwd_direct(ConvFwdArgs a) {
+    const ConvGeom& g = a.g;
+    int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+    int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= So) return;
+    int co0 = blockIdx.y * 8, CoutP = round_up(g.Cout, 8);
+    int x = (int)(v % g.Wo); int64_t r = v / g.Wo;
+    int y = (int)(r % g.Ho); int z = (int)(r / g.Ho);
+    int tap = ((z & 1) * 2 + (y & 1)) * 2 + (x & 1);
+    int64_t vin = ((int64_t)(z >> 1) * g.H + (y >> 1)) * g.W + (x >> 1);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (a.bias && co0 + j < g.Cout) ? a.bias[co0 + j] : 0.f;
+    int cb = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+        const SrcDesc& sd = a.src[s];
+        for (int ci = 0; ci < sd.C; ++ci) {
+            float xv = view_ld<T>(sd, vin, ci);
+            const float* wr = a.w + ((int64_t)tap * g.Cin + cb + ci) * CoutP + co0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv, wr[j], acc[j]);
+        }
+        cb += sd.C;
+    }
+    T* o = (T*)a.out;
+    for (int j = 0; j < 8; ++j)
+        if (co0 + j < g.Cout) st<T>(o, v * g.Cout + co0 + j, acc[j]);
+}
+void launch_convt_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w, const float* bias,
+                             void* out, hipStream_t s) {
+    ConvFwdArgs a;
+    a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
+    a.w = w; a.bias = bias; a.out = out; a.out_ncdhw = nullptr;
+    int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+    dim3 grid(cdiv64(So, 256), (g.Cout + 7) / 8);
+    UNET_DISPATCH(dtype, (k_convt_fwd_direct<T><<<grid, 256, 0, s>>>(a)));
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_convt_dgrad_direct(ConvDgradArgs a) {
+    const ConvGeom& g = a.g;
+    int64_t S = (int64_t)g.D * g.H * g.W;
+    int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= S) return;
+    int ci0 = blockIdx.y * 8, CinP = round_up(g.Cin, 8);
+    int x = (int)(v % g.W); int64_t r = v / g.W;
+    int y = (int)(r % g.H); int z = (int)(r / g.H);
+    const T* dy = (const T*)a.dy;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int tap = 0; tap < 8; ++tap) {
+        int64_t vo = ((int64_t)(2 * z + (tap >> 2)) * g.Ho + (2 * y + ((tap >> 1) & 1))) * g.Wo + (2 * x + (tap & 1));
+        for (int co = 0; co < g.Cout; ++co) {
+            float d = ld<T>(dy, vo * g.Cout + co);
+            const float* wr = a.w + ((int64_t)tap * g.Cout + co) * CinP + ci0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, wr[j], acc[j]);
+        }
+    }
+    for (int j = 0; j < 8; ++j)
+        if (ci0 + j < g.Cin) write_grad<T>(a.dst, a.ndst, v, ci0 + j, acc[j]);
+}
+void launch_convt_dgrad_direct(int dtype, const ConvGeom& g, const void* dy, const float* w, const DstGrad* dst, int ndst,
+                               hipStream_t s) {
+    ConvDgradArgs a;
+    a.g = g; a.dy = dy; a.w = w; a.ndst = ndst; a.dst[0] = dst[0]; if (ndst > 1) a.dst[1] = dst[1];
+    int64_t S = (int64_t)g.D * g.H * g.W;
+    dim3 grid(cdiv64(S, 256), (g.Cin + 7) / 8);
+    UNET_DISPATCH(dtype, (k_convt_dgrad_direct<T><<<grid, 256, 0, s>>>(a)));
+}
+
+}  // namespace unet

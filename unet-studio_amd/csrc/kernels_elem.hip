@@ -1,0 +1,551 @@
+// HBM-bound kernels of the UNet3d path: layout conversion, norm statistics and their backward,
+// pooling / resampling, copies, the fused losses of train.cpp:501-552 and the step epilogue of
+// train.cpp:759-766.  All reductions are two-stage (per-block partials, then a finalize kernel that
+// sums the partials in a fixed order in fp64): deterministic, no float atomics.
+#include "device_util.h"
+
+namespace unet {
+
+// ------------------------------------------------------------------------------------------------
+// layout: fp32 NCDHW <-> channels-last element type
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void k_pack_input(const float* __restrict__ x, T* __restrict__ y, int C, int64_t S) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // output index v*C + c
+    if (i >= S * C) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    st<T>(y, i, x[(int64_t)c * S + v]);
+}
+void launch_pack_input(int dtype, const float* x, void* y, int C, int64_t S, hipStream_t s) {
+    UNET_DISPATCH(dtype, (k_pack_input<T><<<cdiv64(S * C, 256), 256, 0, s>>>(x, (T*)y, C, S)));
+}
+
+template <typename T> __global__ void k_export(SrcDesc src, float* __restrict__ y, int64_t S) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // output index c*S + v (coalesced writes)
+    if (i >= S * src.C) return;
+    int c = (int)(i / S); int64_t v = i % S;
+    y[i] = view_ld<T>(src, v, c);
+}
+void launch_export(int dtype, SrcDesc src, float* y, int64_t S, hipStream_t s) {
+    UNET_DISPATCH(dtype, (k_export<T><<<cdiv64(S * src.C, 256), 256, 0, s>>>(src, y, S)));
+}
+void launch_unpack_ncdhw(int dtype, const void* g, float* out, int C, int64_t S, hipStream_t s) {
+    SrcDesc d;
+    d.ptr = g; d.C = C;
+    launch_export(dtype, d, out, S, s);
+}
+
+template <typename T> __global__ void k_import_grad(const float* __restrict__ g, T* __restrict__ o, int C, int64_t S, int acc) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * C) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    float val = g[(int64_t)c * S + v];
+    if (acc) val += ld<T>(o, i);
+    st<T>(o, i, val);
+}
+void launch_import_grad(int dtype, const float* g, void* o, int C, int64_t S, int accumulate, hipStream_t s) {
+    UNET_DISPATCH(dtype, (k_import_grad<T><<<cdiv64(S * C, 256), 256, 0, s>>>(g, (T*)o, C, S, accumulate)));
+}
+void launch_export_bwd(int dtype, const float* g, DstGrad dst, int64_t S, hipStream_t s) {
+    if (!dst.ptr) return;
+    launch_import_grad(dtype, g, dst.ptr, dst.C, S, dst.accumulate, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// norm statistics.  Block b covers voxels [b*VPB, (b+1)*VPB); threads = (voxel lane) x (channel).
+// ------------------------------------------------------------------------------------------------
+int stats_blocks(int64_t S) {
+    int64_t vpb = (S + 1023) / 1024;
+    if (vpb < 256) vpb = 256;
+    return (int)((S + vpb - 1) / vpb);
+}
+static inline int64_t stats_vpb(int64_t S) {
+    int64_t vpb = (S + 1023) / 1024;
+    return vpb < 256 ? 256 : vpb;
+}
+static inline int pow2_ge(int c) { int p = 1; while (p < c && p < 256) p <<= 1; return p; }
+
+// MODE 0: {sum x, sum x^2};  MODE 1 (norm backward): g <- dv = g*act'(v); {sum dv, sum dv*xhat}
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) k_stats_partial(const T* __restrict__ x, T* __restrict__ gbuf, int C, int64_t S, int64_t VPB,
+                                                       int CW, const float* __restrict__ stat, int act, float* __restrict__ partial) {
+    __shared__ float red[2][256];
+    int NV = 256 / CW, cl = threadIdx.x % CW, lane = threadIdx.x / CW;
+    int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
+    for (int cg = 0; cg < C; cg += CW) {
+        int c = cg + cl;
+        float s1 = 0.f, s2 = 0.f;
+        if (c < C) {
+            float mean = 0.f, rstd = 1.f, sc = 1.f, sh = 0.f;
+            if (MODE == 1) { mean = stat[c]; rstd = stat[C + c]; sc = stat[2 * C + c]; sh = stat[3 * C + c]; }
+            for (int64_t v = v0 + lane; v < v1; v += NV) {
+                float u = ld<T>(x, v * C + c);
+                if (MODE == 0) { s1 += u; s2 = fmaf(u, u, s2); }
+                else {
+                    float dv = ld<T>(gbuf, v * C + c) * act_d(fmaf(u, sc, sh), act);
+                    st<T>(gbuf, v * C + c, dv);
+                    // statistics of the value the apply pass will read back (rounded to T)
+                    dv = ld<T>(gbuf, v * C + c);
+                    s1 += dv; s2 = fmaf(dv, (u - mean) * rstd, s2);
+                }
+            }
+        }
+        red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if (lane == 0 && c < C) {
+            float a = 0.f, b = 0.f;
+            for (int l = 0; l < NV; ++l) { a += red[0][l * CW + cl]; b += red[1][l * CW + cl]; }
+            partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = a;
+            partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
+        }
+        __syncthreads();
+    }
+}
+void launch_stats_partial(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s) {
+    int nb = stats_blocks(S);
+    UNET_DISPATCH(dtype, (k_stats_partial<T, 0><<<nb, 256, 0, s>>>((const T*)x, nullptr, C, S, stats_vpb(S), pow2_ge(C), nullptr, 0, partial)));
+}
+void launch_norm_bwd_partial(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, int act, float* partial,
+                             hipStream_t s) {
+    int nb = stats_blocks(S);
+    UNET_DISPATCH(dtype, (k_stats_partial<T, 1><<<nb, 256, 0, s>>>((const T*)u, (T*)g, C, S, stats_vpb(S), pow2_ge(C), stat, act, partial)));
+}
+
+__device__ __forceinline__ void reduce2_wave(double& a, double& b) {
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+}
+
+// one wave per channel
+__global__ void __launch_bounds__(64) k_norm_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
+                                                      const float* gamma, const float* beta, double eps, float* stat, float* rm,
+                                                      float* rv, double momentum) {
+    int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+    reduce2_wave(a, b);
+    if (threadIdx.x == 0) {
+        double mean = a / (double)S, var = b / (double)S - mean * mean;
+        if (var < 0.0) var = 0.0;
+        double rstd = 1.0 / sqrt(var + eps);
+        double sc = (double)gamma[c] * rstd;
+        stat[c] = (float)mean; stat[C + c] = (float)rstd; stat[2 * C + c] = (float)sc; stat[3 * C + c] = (float)((double)beta[c] - mean * sc);
+        if (rm) {
+            rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mean);
+            rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (S > 1 ? var * (double)S / (double)(S - 1) : var));
+        }
+    }
+}
+void launch_norm_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
+                          float* stat, float* rm, float* rv, double momentum, hipStream_t s) {
+    k_norm_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, beta, eps, stat, rm, rv, momentum);
+}
+
+__global__ void k_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat) {
+    int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double rstd = 1.0 / sqrt((double)rv[c] + eps), sc = (double)gamma[c] * rstd;
+    stat[c] = rm[c]; stat[C + c] = (float)rstd; stat[2 * C + c] = (float)sc; stat[3 * C + c] = (float)((double)beta[c] - (double)rm[c] * sc);
+}
+void launch_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat,
+                      hipStream_t s) {
+    k_norm_eval<<<(C + 63) / 64, 64, 0, s>>>(C, gamma, beta, rm, rv, eps, stat);
+}
+
+__global__ void __launch_bounds__(64) k_norm_bwd_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
+                                                          const float* gamma, const float* stat, float* coef, float* dgamma,
+                                                          float* dbeta) {
+    int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+    reduce2_wave(a, b);
+    if (threadIdx.x == 0) {
+        coef[c] = gamma[c] * stat[C + c];
+        coef[C + c] = (float)(a / (double)S);
+        coef[2 * C + c] = (float)(b / (double)S);
+        dgamma[c] += (float)b;
+        dbeta[c] += (float)a;
+    }
+}
+void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat, float* coef,
+                              float* dgamma, float* dbeta, hipStream_t s) {
+    k_norm_bwd_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, stat, coef, dgamma, dbeta);
+}
+
+template <typename T> __global__ void k_norm_bwd_apply(T* __restrict__ g, const T* __restrict__ u, int C, int64_t n,
+                                                       const float* __restrict__ stat, const float* __restrict__ coef) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i % C);
+    float xh = (ld<T>(u, i) - stat[c]) * stat[C + c];
+    st<T>(g, i, coef[c] * (ld<T>(g, i) - coef[C + c] - xh * coef[2 * C + c]));
+}
+void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, hipStream_t s) {
+    UNET_DISPATCH(dtype, (k_norm_bwd_apply<T><<<cdiv64(S * C, 256), 256, 0, s>>>((T*)g, (const T*)u, C, S * C, stat, coef)));
+}
+
+template <typename T> __global__ void k_act_bwd(T* __restrict__ g, const T* __restrict__ u, int act, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    st<T>(g, i, ld<T>(g, i) * act_d(ld<T>(u, i), act));
+}
+void launch_act_bwd(int dtype, void* g, const void* u, int act, int64_t n, hipStream_t s) {
+    UNET_DISPATCH(dtype, (k_act_bwd<T><<<cdiv64(n, 256), 256, 0, s>>>((T*)g, (const T*)u, act, n)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool3d(2,2) floor mode (unet.cpp:38-39), Upsample nearest x2 (unet.cpp:41-44), copies
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void k_maxpool_fwd(SrcDesc src, T* __restrict__ out, int D, int H, int W) {
+    int Do = D / 2, Ho = H / 2, Wo = W / 2, C = src.C;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Do * Ho * Wo * C) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    int x = (int)(v % Wo); int64_t r = v / Wo;
+    int y = (int)(r % Ho); int z = (int)(r / Ho);
+    float best = -INFINITY;
+    for (int t = 0; t < 8; ++t) {
+        int64_t vi = ((int64_t)(2 * z + (t >> 2)) * H + (2 * y + ((t >> 1) & 1))) * W + (2 * x + (t & 1));
+        float val = view_ld<T>(src, vi, c);
+        if (val > best || val != val) best = val;
+    }
+    st<T>(out, i, best);
+}
+void launch_maxpool_fwd(int dtype, SrcDesc src, void* out, int D, int H, int W, hipStream_t s) {
+    int64_t n = (int64_t)(D / 2) * (H / 2) * (W / 2) * src.C;
+    UNET_DISPATCH(dtype, (k_maxpool_fwd<T><<<cdiv64(n, 256), 256, 0, s>>>(src, (T*)out, D, H, W)));
+}
+// one thread per INPUT element: gradient goes to the first maximum of its window (windows do not overlap)
+template <typename T> __global__ void k_maxpool_bwd(SrcDesc src, const T* __restrict__ gout, DstGrad dst, int D, int H, int W) {
+    int Do = D / 2, Ho = H / 2, Wo = W / 2, C = src.C;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)D * H * W * C) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    int x = (int)(v % W); int64_t r = v / W;
+    int y = (int)(r % H); int z = (int)(r / H);
+    float val = 0.f;
+    int zo = z >> 1, yo = y >> 1, xo = x >> 1;
+    if (zo < Do && yo < Ho && xo < Wo) {
+        float best = -INFINITY; int bt = 0;
+        for (int t = 0; t < 8; ++t) {
+            int64_t vi = ((int64_t)(2 * zo + (t >> 2)) * H + (2 * yo + ((t >> 1) & 1))) * W + (2 * xo + (t & 1));
+            float a = view_ld<T>(src, vi, c);
+            if (a > best || a != a) { best = a; bt = t; }
+        }
+        int mine = ((z & 1) << 2) | ((y & 1) << 1) | (x & 1);
+        if (mine == bt) val = ld<T>(gout, (((int64_t)zo * Ho + yo) * Wo + xo) * C + c);
+    }
+    T* p = (T*)dst.ptr;
+    if (dst.accumulate) val += ld<T>(p, i);
+    st<T>(p, i, val);
+}
+void launch_maxpool_bwd(int dtype, SrcDesc src, const void* gout, DstGrad dst, int D, int H, int W, hipStream_t s) {
+    if (!dst.ptr) return;
+    int64_t n = (int64_t)D * H * W * src.C;
+    UNET_DISPATCH(dtype, (k_maxpool_bwd<T><<<cdiv64(n, 256), 256, 0, s>>>(src, (const T*)gout, dst, D, H, W)));
+}
+
+template <typename T> __global__ void k_upsample_fwd(SrcDesc src, T* __restrict__ out, int D, int H, int W) {
+    int C = src.C;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)8 * D * H * W * C) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    int x = (int)(v % (2 * W)); int64_t r = v / (2 * W);
+    int y = (int)(r % (2 * H)); int z = (int)(r / (2 * H));
+    st<T>(out, i, view_ld<T>(src, ((int64_t)(z >> 1) * H + (y >> 1)) * W + (x >> 1), c));
+}
+void launch_upsample_fwd(int dtype, SrcDesc src, void* out, int D, int H, int W, hipStream_t s) {
+    int64_t n = (int64_t)8 * D * H * W * src.C;
+    UNET_DISPATCH(dtype, (k_upsample_fwd<T><<<cdiv64(n, 256), 256, 0, s>>>(src, (T*)out, D, H, W)));
+}
+template <typename T> __global__ void k_upsample_bwd(const T* __restrict__ gout, DstGrad dst, int D, int H, int W) {
+    int C = dst.C;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)D * H * W * C) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    int x = (int)(v % W); int64_t r = v / W;
+    int y = (int)(r % H); int z = (int)(r / H);
+    float val = 0.f;
+    for (int t = 0; t < 8; ++t)
+        val += ld<T>(gout, (((int64_t)(2 * z + (t >> 2)) * (2 * H) + (2 * y + ((t >> 1) & 1))) * (2 * W) + (2 * x + (t & 1))) * C + c);
+    T* p = (T*)dst.ptr;
+    if (dst.accumulate) val += ld<T>(p, i);
+    st<T>(p, i, val);
+}
+void launch_upsample_bwd(int dtype, const void* gout, DstGrad dst, int D, int H, int W, hipStream_t s) {
+    if (!dst.ptr) return;
+    int64_t n = (int64_t)D * H * W * dst.C;
+    UNET_DISPATCH(dtype, (k_upsample_bwd<T><<<cdiv64(n, 256), 256, 0, s>>>((const T*)gout, dst, D, H, W)));
+}
+
+struct Src2 { SrcDesc s[2]; int n; };
+struct Dst2 { DstGrad d[2]; int n; };
+template <typename T> __global__ void k_materialize(Src2 src, T* __restrict__ out, int C, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    float val = (src.n > 1 && c >= src.s[0].C) ? view_ld<T>(src.s[1], v, c - src.s[0].C) : view_ld<T>(src.s[0], v, c);
+    st<T>(out, i, val);
+}
+void launch_materialize(int dtype, const SrcDesc* src, int nsrc, void* out, int64_t S, hipStream_t s) {
+    Src2 a;
+    a.n = nsrc; a.s[0] = src[0]; if (nsrc > 1) a.s[1] = src[1];
+    int C = src[0].C + (nsrc > 1 ? src[1].C : 0);
+    UNET_DISPATCH(dtype, (k_materialize<T><<<cdiv64(S * C, 256), 256, 0, s>>>(a, (T*)out, C, S * C)));
+}
+template <typename T> __global__ void k_materialize_bwd(const T* __restrict__ gout, Dst2 dst, int C, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = (int)(i % C); int64_t v = i / C;
+    int which = (dst.n > 1 && c >= dst.d[0].C) ? 1 : 0;
+    const DstGrad& d = dst.d[which];
+    if (!d.ptr) return;
+    int64_t j = v * d.C + (which ? c - dst.d[0].C : c);
+    float val = ld<T>(gout, i);
+    T* p = (T*)d.ptr;
+    if (d.accumulate) val += ld<T>(p, j);
+    st<T>(p, j, val);
+}
+void launch_materialize_bwd(int dtype, const void* gout, const DstGrad* dst, int ndst, int64_t S, hipStream_t s) {
+    Dst2 a;
+    a.n = ndst; a.d[0] = dst[0]; if (ndst > 1) a.d[1] = dst[1];
+    int C = dst[0].C + (ndst > 1 ? dst[1].C : 0);
+    UNET_DISPATCH(dtype, (k_materialize_bwd<T><<<cdiv64(S * C, 256), 256, 0, s>>>((const T*)gout, a, C, S * C)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// losses: calc_losses (train.cpp:501-552) over fp32 NCDHW logits and int64 targets
+// ------------------------------------------------------------------------------------------------
+// deep-supervision target pyramid, train.cpp:645-662: nearest, src = min(floor(dst * in/out), in-1)
+__global__ void k_target_half(const int64_t* __restrict__ t, int64_t* __restrict__ o, int D, int H, int W) {
+    int Do = D >> 1, Ho = H >> 1, Wo = W >> 1;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Do * Ho * Wo) return;
+    int x = (int)(i % Wo); int64_t r = i / Wo;
+    int y = (int)(r % Ho); int z = (int)(r / Ho);
+    float sd = (float)D / Do, sh = (float)H / Ho, sw = (float)W / Wo;
+    int iz = min((int)floorf(z * sd), D - 1), iy = min((int)floorf(y * sh), H - 1), ix = min((int)floorf(x * sw), W - 1);
+    o[i] = (int64_t)(float)t[((int64_t)iz * H + iy) * W + ix];
+}
+void launch_target_half(const int64_t* t, int64_t* o, int D, int H, int W, hipStream_t s) {
+    int64_t n = (int64_t)(D >> 1) * (H >> 1) * (W >> 1);
+    k_target_half<<<cdiv64(n, 256), 256, 0, s>>>(t, o, D, H, W);
+}
+
+int loss_blocks(int64_t S) {
+    int64_t nb = (S + 255) / 256;
+    return (int)(nb > 1024 ? 1024 : nb);
+}
+
+// merged logit of class c' under collapse_before k (train.cpp:514-521): c' = 0 is logsumexp of classes 0..k-1
+struct VoxelLogits {
+    const float* p; int64_t S, v; int k; float lse0;
+    __device__ float get(int cp) const { return (k && cp == 0) ? lse0 : p[(int64_t)(k ? cp + k - 1 : cp) * S + v]; }
+};
+__device__ __forceinline__ VoxelLogits make_vl(const float* logits, int64_t S, int64_t v, int k) {
+    VoxelLogits L;
+    L.p = logits; L.S = S; L.v = v; L.k = k; L.lse0 = 0.f;
+    if (k) {
+        float mx = -INFINITY;
+        for (int c = 0; c < k; ++c) mx = fmaxf(mx, logits[(int64_t)c * S + v]);
+        float s = 0.f;
+        for (int c = 0; c < k; ++c) s += expf(logits[(int64_t)c * S + v] - mx);
+        L.lse0 = mx + logf(s);
+    }
+    return L;
+}
+__device__ __forceinline__ float clamp_p(float q) { return fminf(fmaxf(q, 1e-6f), 1.0f - 1e-6f); }
+
+// partial layout per block: [0] ce, [1] mse, [2] nvalid, [3 .. 3+oc) inter, [3+oc .. 3+2oc) card
+__global__ void __launch_bounds__(256) k_loss_partial(const float* __restrict__ logits, const int64_t* __restrict__ target, int C,
+                                                      int64_t S, int k, float* __restrict__ partial) {
+    extern __shared__ float sh[];  // 3 + 2*oc
+    int oc = k ? C - k + 1 : C;
+    int np = 3 + 2 * oc;
+    for (int i = threadIdx.x; i < np; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    float ce = 0.f, mse = 0.f, nv = 0.f;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < S; v += (int64_t)gridDim.x * 256) {
+        int64_t t = target[v];
+        bool valid = t < C;
+        if (!valid) continue;  // invalid voxels carry weight 0 in every term (train.cpp:523-550)
+        int tt = k ? (int)(t - k + 1 > 0 ? t - k + 1 : 0) : (int)t;
+        VoxelLogits L = make_vl(logits, S, v, k);
+        float mx = -INFINITY;
+        for (int c = 0; c < oc; ++c) mx = fmaxf(mx, L.get(c));
+        float sum = 0.f;
+        for (int c = 0; c < oc; ++c) sum += expf(L.get(c) - mx);
+        float inv = 1.f / sum, psq = 0.f, pt = 0.f;
+        for (int c = 0; c < oc; ++c) {
+            float p = clamp_p(expf(L.get(c) - mx) * inv);
+            psq = fmaf(p, p, psq);
+            if (c == tt) pt = p;
+            if (c >= 1) atomicAdd(&sh[3 + oc + c], p + (c == tt ? 1.f : 0.f));
+        }
+        if (tt >= 1) atomicAdd(&sh[3 + tt], pt);
+        ce += -(L.get(tt) - mx - logf(sum));
+        mse += psq - 2.f * pt + 1.f;
+        nv += 1.f;
+    }
+    atomicAdd(&sh[0], ce); atomicAdd(&sh[1], mse); atomicAdd(&sh[2], nv);
+    __syncthreads();
+    for (int i = threadIdx.x; i < np; i += 256) partial[(int64_t)blockIdx.x * np + i] = sh[i];
+}
+void launch_loss_partial(const float* logits, const int64_t* target, int C, int64_t S, int collapse, float* partial, hipStream_t s) {
+    int oc = collapse ? C - collapse + 1 : C;
+    k_loss_partial<<<loss_blocks(S), 256, (3 + 2 * oc) * sizeof(float), s>>>(logits, target, C, S, collapse, partial);
+}
+
+// level_out: [0] ce [1] dice [2] mse [3] n  [4 .. 4+oc) inter  [4+oc .. 4+2oc) card
+// totals: [0] total loss (accumulated over levels) [1..3] level-0 ce, dice, mse
+__global__ void __launch_bounds__(256) k_loss_finalize(const float* __restrict__ partial, int nblk, int oc, float weight, int cost_mask,
+                                                       float* level_out, float* totals, int set_stats) {
+    extern __shared__ double shd[];  // 3 + 2*oc
+    int np = 3 + 2 * oc;
+    for (int i = threadIdx.x; i < np; i += 256) {
+        double a = 0.0;
+        for (int b = 0; b < nblk; ++b) a += partial[(int64_t)b * np + i];
+        shd[i] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double n = shd[2] < 1.0 ? 1.0 : shd[2];
+        double eps = (double)1e-5f, dsum = 0.0;
+        for (int c = 1; c < oc; ++c) dsum += (2.0 * shd[3 + c] + eps) / (shd[3 + oc + c] + eps);
+        double ce = shd[0] / n, mse = shd[1] / n, dice = 1.0 - dsum / (double)(oc - 1 > 1 ? oc - 1 : 1);
+        level_out[0] = (float)ce; level_out[1] = (float)dice; level_out[2] = (float)mse; level_out[3] = (float)n;
+        for (int c = 0; c < oc; ++c) { level_out[4 + c] = (float)shd[3 + c]; level_out[4 + oc + c] = (float)shd[3 + oc + c]; }
+        double sel = 0.0;
+        if (!(cost_mask & 7)) sel = ce;
+        else sel = ((cost_mask & 1) ? ce : 0.0) + ((cost_mask & 2) ? dice : 0.0) + ((cost_mask & 4) ? mse : 0.0);
+        totals[0] += (float)(weight * sel);
+        if (set_stats) { totals[1] = (float)ce; totals[2] = (float)dice; totals[3] = (float)mse; }
+    }
+}
+void launch_loss_finalize(const float* partial, int nblk, int oc, float weight, int cost_mask, float* level_out, float* totals,
+                          int set_stats, hipStream_t s) {
+    k_loss_finalize<<<1, 256, (3 + 2 * oc) * sizeof(double), s>>>(partial, nblk, oc, weight, cost_mask, level_out, totals, set_stats);
+}
+
+__global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ logits, const int64_t* __restrict__ target, int C, int64_t S,
+                                                   int k, const float* __restrict__ level_out, float weight, int cost_mask,
+                                                   float* __restrict__ dlogits) {
+    int oc = k ? C - k + 1 : C;
+    int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= S) return;
+    int64_t t = target[v];
+    if (!(t < C)) {
+        for (int c = 0; c < C; ++c) dlogits[(int64_t)c * S + v] = 0.f;
+        return;
+    }
+    float w_ce = (!(cost_mask & 7) || (cost_mask & 1)) ? weight : 0.f;
+    float w_dice = (cost_mask & 2) ? weight : 0.f, w_mse = (cost_mask & 4) ? weight : 0.f;
+    float n = level_out[3];
+    const float* inter = level_out + 4;
+    const float* card = level_out + 4 + oc;
+    float dden = (float)(oc - 1 > 1 ? oc - 1 : 1), eps = 1e-5f;
+    int tt = k ? (int)(t - k + 1 > 0 ? t - k + 1 : 0) : (int)t;
+    VoxelLogits L = make_vl(logits, S, v, k);
+    float mx = -INFINITY;
+    for (int c = 0; c < oc; ++c) mx = fmaxf(mx, L.get(c));
+    float sum = 0.f;
+    for (int c = 0; c < oc; ++c) sum += expf(L.get(c) - mx);
+    float inv = 1.f / sum;
+    // pass A: dot = sum_c dprob_c * q_c
+    float dot = 0.f;
+    for (int c = 0; c < oc; ++c) {
+        float q = expf(L.get(c) - mx) * inv, p = clamp_p(q), g = 0.f;
+        g += w_mse * (2.f * p - (c == tt ? 2.f : 0.f)) / n;
+        if (c >= 1) {
+            float m = c == tt ? 1.f : 0.f, den = card[c] + eps;
+            g += w_dice * (-(2.f * m * den - (2.f * inter[c] + eps)) / (den * den)) / dden;
+        }
+        if (!(q >= 1e-6f && q <= 1.0f - 1e-6f)) g = 0.f;  // clamp has zero gradient outside its range
+        dot = fmaf(g, q, dot);
+    }
+    // pass B: dlogit_c = q_c*(dprob_c - dot) + w_ce*(q_c - [c==t])/n
+    float d0 = 0.f;
+    for (int c = 0; c < oc; ++c) {
+        float q = expf(L.get(c) - mx) * inv, p = clamp_p(q), g = 0.f;
+        g += w_mse * (2.f * p - (c == tt ? 2.f : 0.f)) / n;
+        if (c >= 1) {
+            float m = c == tt ? 1.f : 0.f, den = card[c] + eps;
+            g += w_dice * (-(2.f * m * den - (2.f * inter[c] + eps)) / (den * den)) / dden;
+        }
+        if (!(q >= 1e-6f && q <= 1.0f - 1e-6f)) g = 0.f;
+        float dl = q * (g - dot) + w_ce * (q - (c == tt ? 1.f : 0.f)) / n;
+        if (k && c == 0) d0 = dl;
+        else dlogits[(int64_t)(k ? c + k - 1 : c) * S + v] = dl;
+    }
+    if (k) {
+        float m0 = -INFINITY;
+        for (int c = 0; c < k; ++c) m0 = fmaxf(m0, logits[(int64_t)c * S + v]);
+        float s0 = 0.f;
+        for (int c = 0; c < k; ++c) s0 += expf(logits[(int64_t)c * S + v] - m0);
+        for (int c = 0; c < k; ++c) dlogits[(int64_t)c * S + v] = d0 * expf(logits[(int64_t)c * S + v] - m0) / s0;
+    }
+}
+void launch_loss_grad(const float* logits, const int64_t* target, int C, int64_t S, int collapse, const float* level_out, float weight,
+                      int cost_mask, float* dlogits, hipStream_t s) {
+    k_loss_grad<<<cdiv64(S, 256), 256, 0, s>>>(logits, target, C, S, collapse, level_out, weight, cost_mask, dlogits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// step epilogue (train.cpp:759-766, unet.cpp:254-275)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__ g, int64_t n, float scale, float* __restrict__ partial) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (int64_t)gridDim.x * 1024) {
+        float r = 0.f;
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < n) { float x = g[i0 + j] * scale; r = fmaf(x, x, r); }
+        acc += (double)r;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = (float)red[0];
+}
+void launch_sumsq_partial(const float* g, int64_t n, float scale, float* partial, int nblk, hipStream_t s) {
+    k_sumsq_partial<<<nblk, 256, 0, s>>>(g, n, scale, partial);
+}
+
+__global__ void __launch_bounds__(256) k_sgd(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, int64_t n,
+                                             const SgdSeg* __restrict__ segs, int nseg, const float* __restrict__ partial, int nblk,
+                                             float lr, float momentum, int nesterov, float wdecay, float clip_norm, float grad_scale, float* norm_out) {
+    __shared__ float s_coef;
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int b = 0; b < nblk; ++b) tot += partial[b];
+        float norm = (float)sqrt(tot);
+        float coef = clip_norm / (norm + 1e-6f);
+        s_coef = coef > 1.f ? 1.f : coef;
+        if (blockIdx.x == 0 && norm_out) *norm_out = norm;
+    }
+    __syncthreads();
+    float coef = s_coef * grad_scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        int lo = 0, hi = nseg - 1;
+        while (lo < hi) {  // last segment with offset <= i
+            int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].offset <= i) lo = mid; else hi = mid - 1;
+        }
+        float wd = segs[lo].wd * wdecay;
+        float pv = p[i];
+        float d = fmaf(wd, pv, g[i] * coef);
+        float b = fmaf(momentum, m[i], d);
+        m[i] = b;
+        p[i] = pv - lr * (nesterov ? fmaf(momentum, b, d) : b);
+        g[i] = 0.f;
+    }
+}
+void launch_sgd(float* p, float* g, float* m, int64_t n, const SgdSeg* segs, int nseg, const float* partial, int nblk, float lr,
+                float momentum, int nesterov, float wdecay, float clip_norm, float grad_scale, float* norm_out, hipStream_t s) {
+    int64_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    k_sgd<<<(unsigned)nb, 256, 0, s>>>(p, g, m, n, segs, nseg, partial, nblk, lr, momentum, nesterov, wdecay, clip_norm, grad_scale, norm_out);
+}
+
+}  // namespace unet

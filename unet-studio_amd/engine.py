@@ -1,0 +1,143 @@
+"""ctypes binding of libunet_hip.so (include/unet_hip.h).
+
+This is the only way Python reaches the compute path: there is no fallback.  If the shared library is
+missing or fails to load, importing this module raises -- the product path must fail loudly rather
+than run anything else (the oracle is test infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+IMPL_AUTO, IMPL_DIRECT = 0, 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libunet_hip.so not found at %s: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+        "or unet-studio_amd/csrc/build.sh); there is no CPU fallback" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+_pp = C.POINTER(C.c_void_p)
+
+
+def _sig(name, res, *args):
+    fn = getattr(lib, name)
+    fn.restype = res
+    fn.argtypes = list(args)
+    return fn
+
+
+_sig("unet_last_error", C.c_char_p)
+_sig("unet_init", _i, C.POINTER(_i))
+_sig("unet_device_info", _i, _i, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i))
+_sig("unet_plan_create", _i, C.c_char_p, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp))
+_sig("unet_plan_destroy", None, _vp)
+_sig("unet_plan_param_count", _i, _vp, C.POINTER(_i))
+_sig("unet_plan_param_shape", _i, _vp, _i, C.POINTER(C.c_int64), C.POINTER(_i))
+_sig("unet_plan_param_decay", _i, _vp, _i, C.POINTER(_i))
+_sig("unet_plan_param_fan_in", _i, _vp, _i, C.POINTER(C.c_int64), C.POINTER(_i))
+_sig("unet_plan_buffer_count", _i, _vp, C.POINTER(_i))
+_sig("unet_plan_buffer_shape", _i, _vp, _i, C.POINTER(C.c_int64))
+_sig("unet_plan_output_count", _i, _vp, C.POINTER(_i))
+_sig("unet_plan_output_shape", _i, _vp, _i, C.POINTER(C.c_int64))
+_sig("unet_plan_workspace_bytes", _i, _vp, C.POINTER(_sz))
+_sig("unet_plan_flops", _i, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double))
+_sig("unet_plan_describe", _sz, _vp, C.c_char_p, _sz)
+_sig("unet_forward", _i, _vp, _pp, _pp, _vp, _pp, _vp, _i, _vp)
+_sig("unet_backward", _i, _vp, _pp, _pp, _pp, _vp, _vp, _vp)
+_sig("unet_loss_scratch_bytes", _i, _vp, C.POINTER(_sz))
+_sig("unet_loss", _i, _vp, _pp, _vp, _i, _i, _pp, _vp, _vp, _vp)
+_sig("unet_sgd_step", _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _f, _vp, _vp, _vp)
+_sig("unet_op_scratch_bytes", _i, _i, _i, _i, _i, _i, C.POINTER(_sz))
+_sig("unet_op_conv3d_fwd", _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
+_sig("unet_op_conv3d_bwd_data", _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
+_sig("unet_op_conv3d_bwd_weight", _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
+_sig("unet_op_convt_fwd", _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp)
+_sig("unet_op_convt_bwd_data", _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp)
+_sig("unet_op_convt_bwd_weight", _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp)
+_sig("unet_op_pack_ndhwc", _i, _i, _vp, _vp, _i, C.c_int64, _vp)
+_sig("unet_op_unpack_ncdhw", _i, _i, _vp, _vp, _i, C.c_int64, _vp)
+
+# every symbol include/unet_hip.h declares (tests check that the library exports all of them)
+EXPORTS = [
+    "unet_last_error", "unet_init", "unet_device_info", "unet_plan_create", "unet_plan_destroy", "unet_plan_param_count",
+    "unet_plan_param_shape", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
+    "unet_plan_buffer_shape", "unet_plan_output_count", "unet_plan_output_shape", "unet_plan_workspace_bytes",
+    "unet_plan_flops", "unet_plan_describe", "unet_forward", "unet_backward", "unet_loss_scratch_bytes", "unet_loss",
+    "unet_sgd_step", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
+    "unet_op_convt_fwd", "unet_op_convt_bwd_data", "unet_op_convt_bwd_weight", "unet_op_pack_ndhwc", "unet_op_unpack_ncdhw",
+]
+
+
+class UNetError(RuntimeError):
+    """What the C++ host rethrows as std::runtime_error (unet.cpp:53,66,88,117)."""
+
+
+def check(rc):
+    if rc != 0:
+        raise UNetError(lib.unet_last_error().decode("utf-8", "replace"))
+
+
+def ptr_array(ptrs):
+    """host array of device pointers (None -> NULL)"""
+    arr = (C.c_void_p * max(1, len(ptrs)))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr
+
+
+class Plan:
+    """unet_plan: architecture DSL bound to one input size, element type and device."""
+
+    def __init__(self, arch, in_c, out_c, size, dtype=DTYPE_BF16, device=0, impl=IMPL_AUTO):
+        self.handle = C.c_void_p()
+        D, H, W = size
+        check(lib.unet_plan_create(arch.encode(), in_c, out_c, D, H, W, dtype, device, impl, C.byref(self.handle)))
+        self.arch, self.in_c, self.out_c, self.size, self.dtype, self.device = arch, in_c, out_c, (D, H, W), dtype, device
+        n = C.c_int()
+        check(lib.unet_plan_param_count(self.handle, C.byref(n)))
+        self.param_shapes, self.param_decay, self.param_fan_in, self.param_is_norm_weight = [], [], [], []
+        dims, nd, dec, fan, isn = (C.c_int64 * 5)(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        for i in range(n.value):
+            check(lib.unet_plan_param_shape(self.handle, i, dims, C.byref(nd)))
+            self.param_shapes.append(tuple(dims[k] for k in range(nd.value)))
+            check(lib.unet_plan_param_decay(self.handle, i, C.byref(dec)))
+            self.param_decay.append(bool(dec.value))
+            check(lib.unet_plan_param_fan_in(self.handle, i, C.byref(fan), C.byref(isn)))
+            self.param_fan_in.append(fan.value)
+            self.param_is_norm_weight.append(bool(isn.value))
+        check(lib.unet_plan_buffer_count(self.handle, C.byref(n)))
+        self.buffer_numel = []
+        ne = C.c_int64()
+        for i in range(n.value):
+            check(lib.unet_plan_buffer_shape(self.handle, i, C.byref(ne)))
+            self.buffer_numel.append(ne.value)
+        check(lib.unet_plan_output_count(self.handle, C.byref(n)))
+        self.output_shapes = []
+        for l in range(n.value):
+            check(lib.unet_plan_output_shape(self.handle, l, dims))
+            self.output_shapes.append(tuple(dims[k] for k in range(5)))
+        b = C.c_size_t()
+        check(lib.unet_plan_workspace_bytes(self.handle, C.byref(b)))
+        self.workspace_bytes = b.value
+        check(lib.unet_loss_scratch_bytes(self.handle, C.byref(b)))
+        self.loss_scratch_bytes = b.value
+        f, g = C.c_double(), C.c_double()
+        check(lib.unet_plan_flops(self.handle, C.byref(f), C.byref(g)))
+        self.flops_fwd, self.flops_bwd = f.value, g.value
+
+    def describe(self):
+        n = lib.unet_plan_describe(self.handle, None, 0)
+        buf = C.create_string_buffer(n)
+        lib.unet_plan_describe(self.handle, buf, n)
+        return buf.value.decode()
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value:
+            lib.unet_plan_destroy(h)
+            self.handle = C.c_void_p()

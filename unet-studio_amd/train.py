@@ -1,0 +1,87 @@
+"""Host-side mirror of the reference's training step (train.hpp:8-30, train.cpp:554-805), data parallel.
+
+One process per GPU.  The `batch_size` single-volume micro-steps of one optimizer step ("epoch",
+train.cpp:562,778) are split statically over the ranks (b % world_size == rank), which is equivalent to
+the reference's dynamic stealing (train.cpp:604-606) because the step sums all sample gradients before
+use (train.cpp:756-761).  The reference's reduce-to-root + per-step broadcast (unet.cpp:224-244,
+train.cpp:573-579) becomes ONE sum all-reduce of the flat fp32 gradient buffer over RCCL/xGMI, after
+which every rank applies the identical update -- no broadcast needed.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+class TrainingParam:
+    """training_param, train.hpp:8-30 (the fields the step loop reads)."""
+
+    def __init__(self, batch_size=32, epoch=10000, learning_rate=0.001, seed=0, cost_ce=True, cost_dice=True, cost_mse=True):
+        self.batch_size, self.epoch, self.learning_rate, self.seed = batch_size, epoch, learning_rate, seed
+        self.cost_ce, self.cost_dice, self.cost_mse = cost_ce, cost_dice, cost_mse
+
+
+class SyntheticVolumes:
+    """Stands in for the reader/augmentation threads (train.cpp:267-485, out of scope): seeded synthetic
+    samples born on the device.  image U[0,1) fp32 {1,in,D,H,W}; label U{0..out-1} int64 {1,D,H,W};
+    seed = sample index, like in_file_seed (train.cpp:439)."""
+
+    def __init__(self, in_count, out_count, size, device, base_seed=0, cache=0):
+        self.in_count, self.out_count, self.size, self.device, self.base_seed = in_count, out_count, tuple(size), device, base_seed
+        self._cache, self._cache_n = {}, cache
+
+    def __call__(self, index):
+        if index in self._cache:
+            return self._cache[index]
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.base_seed + index)
+        x = torch.rand((1, self.in_count) + self.size, generator=g, device=self.device, dtype=torch.float32)
+        t = torch.randint(0, self.out_count, (1,) + self.size, generator=g, device=self.device, dtype=torch.int64)
+        if len(self._cache) < self._cache_n:
+            self._cache[index] = (x, t)
+        return x, t
+
+
+class Trainer:
+    """train_unet's thread C (train.cpp:554-805) for one rank."""
+
+    def __init__(self, model, param, source, rank=0, world_size=1, group=None):
+        self.model, self.param, self.source = model, param, source
+        self.rank, self.world_size, self.group = rank, world_size, group
+        self.cur_epoch = 0
+        model.train()
+        if model.optimizer is None:
+            model.create_optimizer(param.learning_rate)  # train.cpp:942
+        self._stats = torch.zeros(4, dtype=torch.float32, device=model.device())
+
+    def lr_at(self, epoch):
+        """train.cpp:566."""
+        return self.param.learning_rate * math.pow(1.0 - float(epoch) / self.param.epoch, 0.9)
+
+    def step(self):
+        """one optimizer step: train.cpp:562-789 without validation / checkpoint I/O"""
+        p, m = self.param, self.model
+        cur_data_index = self.cur_epoch * p.batch_size
+        for g in m.optimizer.param_groups:
+            g["lr"] = self.lr_at(self.cur_epoch)
+        self._stats.zero_()
+        count = 0
+        for b in range(self.rank, p.batch_size, self.world_size):
+            x, t = self.source(cur_data_index + b)
+            losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse)
+            self._stats += losses
+            count += 1
+        if self.world_size > 1:
+            # gradient sum over replicas (unet.cpp:224-244 -> one RCCL all-reduce of the flat buffer)
+            dist.all_reduce(m.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self._stats, op=dist.ReduceOp.SUM, group=self.group)  # loss-stat gather, train.cpp:732-741
+        m.optimizer.step(grad_scale=1.0 / p.batch_size, clip_norm=12.0)  # train.cpp:759-766
+        self.cur_epoch += 1
+        return self._stats
+
+    def record_errors(self):
+        """train.cpp:743-752: append the step's mean (ce, dice, mse) -- a host sync, call it sparingly"""
+        e = (self._stats[1:4] / float(self.param.batch_size)).tolist()
+        with self.model.error_mutex:
+            self.model.training_errors.extend(e)
+        return e
