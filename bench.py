@@ -62,10 +62,14 @@ def dominant_kernel(U, size, dtype_name, iters=10):
     return flops, sec
 
 
-def cpu_baseline(size, budget_steps=2):
+def cpu_baseline(size, budget_steps=1):
     """ATen-CPU train micro-step (forward + losses + backward + step epilogue), fp32, all host cores."""
     from oracle import aten_ref as A
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))   # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = A.UNet3dRef(1, 6, A.default_feature(6))

@@ -56,6 +56,9 @@ def q(x, dt):  # what the engine sees after rounding its input to the element ty
 CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     (1, 16, (9, 10, 12), 3, 1), (16, 16, (8, 8, 16), 3, 1), (5, 7, (6, 7, 9), 3, 1), (16, 32, (8, 10, 12), 3, 2),
     (3, 4, (7, 9, 11), 3, 2), (16, 6, (5, 6, 7), 1, 1), (32, 16, (4, 8, 16), 3, 1), (24, 40, (5, 5, 6), 3, 1),
+    # MFMA-eligible shapes: every tile configuration (W >= 12, 5..11, <= 4), both channel-chunk widths, NT 1/2/4, ragged edges
+    (32, 32, (9, 7, 20), 3, 1), (64, 64, (6, 9, 8), 3, 1), (48, 16, (5, 6, 4), 3, 1), (16, 48, (12, 12, 13), 3, 1),
+    (128, 64, (4, 4, 4), 3, 1), (16, 16, (3, 5, 7), 3, 1), (32, 16, (16, 16, 32), 3, 1),
 ]
 
 

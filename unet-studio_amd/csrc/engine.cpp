@@ -49,6 +49,8 @@ struct unet_plan {
     std::vector<size_t> t_off, g_off;        // tensor storage / gradient storage (SIZE_MAX: none)
     std::vector<size_t> n_stat, n_coef;      // per norm: 4C / 3C floats
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
+    std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
+    std::vector<char> use_mfma;              // per op
     size_t partial_off = 0, partial_bytes = 0;
     size_t ws_bytes = 0;
     // loss scratch layout
@@ -60,6 +62,15 @@ struct unet_plan {
 
     ~unet_plan() {
         if (segs_dev) (void)hipFree(segs_dev);
+    }
+
+    ConvGeom op_geom_of(const Op& op) const {
+        const Tensor& a = g.tensors[op.src[0]];
+        const Tensor& o = g.tensors[op.dst];
+        ConvGeom cg;
+        cg.Cin = op.cin; cg.Cout = op.cout; cg.D = a.D; cg.H = a.H; cg.W = a.W; cg.Do = o.D; cg.Ho = o.H; cg.Wo = o.W;
+        cg.ks = op.ks; cg.stride = op.stride;
+        return cg;
     }
 
     void layout() {
@@ -79,16 +90,33 @@ struct unet_plan {
             size_t pb = (size_t)stats_blocks(g.tensors[g.norms[i].tensor].voxels()) * g.norms[i].C * 2 * 4;
             if (pb > pmax) pmax = pb;
         }
-        partial_bytes = pmax ? pmax : 256;
-        partial_off = take(partial_bytes);
         w_fwd.assign(g.ops.size(), SIZE_MAX); w_dgrad.assign(g.ops.size(), SIZE_MAX);
+        wm_fwd.assign(g.ops.size(), SIZE_MAX); wm_dgrad.assign(g.ops.size(), SIZE_MAX);
+        use_mfma.assign(g.ops.size(), 0);
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
             int k3 = op.kind == OP_CONV ? op.ks * op.ks * op.ks : 8;
             w_fwd[i] = take((size_t)k3 * op.cin * round_up(op.cout, 8) * 4);
             w_dgrad[i] = take((size_t)k3 * op.cout * round_up(op.cin, 8) * 4);
+            if (op.kind == OP_CONV && impl == UNET_IMPL_AUTO && op.out_level < 0) {
+                ConvGeom cg = op_geom_of(op);
+                SrcDesc sd[2];
+                for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
+                if (mfma_conv_fwd_supported(dtype, cg, sd, op.nsrc)) {
+                    use_mfma[i] = 1;
+                    wm_fwd[i] = take(mfma_conv_w_bytes(cg));
+                    ConvGeom t = cg; t.Cin = cg.Cout; t.Cout = cg.Cin;
+                    wm_dgrad[i] = take(mfma_conv_w_bytes(t));
+                    if (g.tensors[op.dst].norm >= 0) {
+                        size_t pb = (size_t)mfma_conv_blocks(cg) * op.cout * 2 * 4;
+                        if (pb > pmax) pmax = pb;
+                    }
+                }
+            }
         }
+        partial_bytes = pmax ? pmax : 256;
+        partial_off = take(partial_bytes);
         ws_bytes = off;
     }
 };
@@ -125,6 +153,7 @@ struct Exec {
 
     void forward(const float* const* params, float* const* buffers, const float* x, float* const* outs, int mode) {
         const Graph& g = p.g;
+        std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             switch (op.kind) {
@@ -138,7 +167,14 @@ struct Exec {
                     ConvGeom cg = geom(op);
                     float* wf = (float*)(ws + p.w_fwd[i]);
                     float* wd = (float*)(ws + p.w_dgrad[i]);
-                    if (op.kind == OP_CONV) {
+                    if (op.kind == OP_CONV && p.use_mfma[i]) {
+                        launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i], mode == 1 ? ws + p.wm_dgrad[i] : nullptr, cg, s);
+                        const Tensor& T = g.tensors[op.dst];
+                        bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
+                        launch_mfma_conv_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst),
+                                             want_stats ? partial() : nullptr, s);
+                        if (want_stats) fused_blocks[T.norm] = mfma_conv_blocks(cg);
+                    } else if (op.kind == OP_CONV) {
                         launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
                                                op.out_level >= 0 ? outs[op.out_level] : nullptr, s);
@@ -155,8 +191,12 @@ struct Exec {
                         launch_norm_eval(n.C, params[n.gamma], params[n.beta], buffers[n.buffer], buffers[n.buffer + 1], n.eps,
                                          stat(op.norm), s);
                     } else {
-                        launch_stats_partial(p.dtype, tptr(n.tensor), n.C, T.voxels(), partial(), s);
-                        launch_norm_finalize(partial(), stats_blocks(T.voxels()), n.C, T.voxels(), params[n.gamma], params[n.beta],
+                        int nb = fused_blocks[op.norm];
+                        if (!nb) {
+                            launch_stats_partial(p.dtype, tptr(n.tensor), n.C, T.voxels(), partial(), s);
+                            nb = stats_blocks(T.voxels());
+                        }
+                        launch_norm_finalize(partial(), nb, n.C, T.voxels(), params[n.gamma], params[n.beta],
                                              n.eps, stat(op.norm), n.batch ? buffers[n.buffer] : nullptr,
                                              n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, s);
                     }
@@ -241,7 +281,8 @@ struct Exec {
                     bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
                     if (op.kind == OP_CONV) {
                         launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
-                        if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
+                        if (any && p.use_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        else if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
                         launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
                         if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
@@ -501,7 +542,8 @@ int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, f
 // ---- single-op surface ----
 int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes) {
     (void)D; (void)H; (void)W;
-    *bytes = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096;
+    *bytes = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096 +
+             align_up((size_t)28 * round_up(cin, 32) * round_up(cout, 32) * 2);
     return 0;
 }
 
@@ -526,25 +568,36 @@ static void op_pack(const float* w, int cin, int cout, int k3, bool transposed, 
 int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D, int H,
                        int W, int ks, int stride, void* scratch, void* stream) {
     OP_TRY({
-        (void)impl;
         hipStream_t s = (hipStream_t)stream;
         ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
         float *wf, *wd;
-        op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
         SrcDesc sd; sd.ptr = x; sd.C = cin;
-        launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+        if (impl == UNET_IMPL_AUTO && mfma_conv_fwd_supported(dtype, g, &sd, 1)) {
+            void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
+            launch_mfma_pack_conv_w(w, wm, nullptr, g, s);
+            launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, nullptr, s);
+        } else {
+            op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
+            launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+        }
     })
 }
 int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H, int W,
                             int ks, int stride, void* scratch, void* stream) {
     OP_TRY({
-        (void)impl;
         hipStream_t s = (hipStream_t)stream;
         ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
         float *wf, *wd;
-        op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
         DstGrad d; d.ptr = dx; d.C = cin; d.accumulate = 0;
-        launch_conv_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
+        SrcDesc sd; sd.C = cin;
+        if (impl == UNET_IMPL_AUTO && mfma_conv_fwd_supported(dtype, g, &sd, 1)) {
+            void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
+            launch_mfma_pack_conv_w(w, nullptr, wm, g, s);
+            launch_mfma_conv_dgrad(g, dy, wm, &d, 1, s);
+        } else {
+            op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
+            launch_conv_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
+        }
     })
 }
 int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout, int D,

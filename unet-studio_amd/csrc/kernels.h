@@ -118,5 +118,9 @@ size_t mfma_conv_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
 void launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
                           float* stats_partial, hipStream_t s);
+// number of thread blocks (= statistics partials) launch_mfma_conv_fwd uses for this geometry
+int mfma_conv_blocks(const ConvGeom& g);
+// dgrad of a stride-1 3x3x3 conv (g = forward geometry); same support condition as the forward kernel
+void launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
 
 }  // namespace unet
