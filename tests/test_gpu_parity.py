@@ -39,9 +39,9 @@ def from_cl(t):  # device [D,H,W,C] -> numpy [C,D,H,W] fp32
     return np.ascontiguousarray(np.transpose(t.float().cpu().numpy(), (3, 0, 1, 2)))
 
 
-def scratch(cin, cout):
+def scratch(cin, cout, D=1, H=1, W=1):
     b = C.c_size_t()
-    E.check(E.lib.unet_op_scratch_bytes(cin, cout, 1, 1, 1, C.byref(b)))
+    E.check(E.lib.unet_op_scratch_bytes(cin, cout, D, H, W, C.byref(b)))
     return torch.empty(b.value, dtype=torch.uint8, device=DEV)
 
 
@@ -59,6 +59,8 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     # MFMA-eligible shapes: every tile configuration (W >= 12, 5..11, <= 4), both channel-chunk widths, NT 1/2/4, ragged edges
     (32, 32, (9, 7, 20), 3, 1), (64, 64, (6, 9, 8), 3, 1), (48, 16, (5, 6, 4), 3, 1), (16, 48, (12, 12, 13), 3, 1),
     (128, 64, (4, 4, 4), 3, 1), (16, 16, (3, 5, 7), 3, 1), (32, 16, (16, 16, 32), 3, 1),
+    # stride-2 MFMA wgrad: every tile configuration (Wo >= 12, 5..11, <= 4), PJ 1/2/4, odd input sizes
+    (16, 32, (12, 16, 32), 3, 2), (32, 64, (9, 11, 13), 3, 2), (64, 16, (8, 8, 8), 3, 2), (16, 16, (5, 7, 25), 3, 2),
 ]
 
 
@@ -73,7 +75,7 @@ def test_conv3d_ops(case, dt, impl):
     od = [(s + 2 * pad - ks) // st + 1 for s in (D, H, W)]
     y_ref = np.empty((cout, *od), np.float32)
     l.orc_conv3d_fwd(O._f(x), O._f(w), O._f(b), O._f(y_ref), cin, cout, D, H, W, ks, st)
-    sc = scratch(cin, cout)
+    sc = scratch(cin, cout, D, H, W)
     wd, bd = torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV)
     xd = to_cl(x, dt)
     yd = torch.empty((*od, cout), dtype=TDT[dt], device=DEV)

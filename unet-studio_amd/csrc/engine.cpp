@@ -51,6 +51,8 @@ struct unet_plan {
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
     std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
     std::vector<char> use_mfma;              // per op
+    std::vector<char> wgrad_mfma;            // per op: wgrad runs on the MFMA kernel
+    size_t wgrad_off = 0;
     size_t partial_off = 0, partial_bytes = 0;
     size_t ws_bytes = 0;
     // loss scratch layout
@@ -117,6 +119,22 @@ struct unet_plan {
         }
         partial_bytes = pmax ? pmax : 256;
         partial_off = take(partial_bytes);
+        // MFMA wgrad: one shared slab scratch (ops run one after another on the stream)
+        wgrad_mfma.assign(g.ops.size(), 0);
+        size_t wmax = 0;
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV || impl != UNET_IMPL_AUTO) continue;
+            ConvGeom cg = op_geom_of(op);
+            SrcDesc sd[2];
+            for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
+            if (mfma_wgrad_supported(dtype, cg, sd, op.nsrc)) {
+                wgrad_mfma[i] = 1;
+                size_t b = mfma_wgrad_scratch_bytes(cg);
+                if (b > wmax) wmax = b;
+            }
+        }
+        wgrad_off = take(wmax ? wmax : 256);
         ws_bytes = off;
     }
 };
@@ -280,7 +298,10 @@ struct Exec {
                     const float* wd = (const float*)(ws + p.w_dgrad[i]);
                     bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
                     if (op.kind == OP_CONV) {
-                        launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
+                        if (p.wgrad_mfma[i])
+                            launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                        else
+                            launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
                         if (any && p.use_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
@@ -541,9 +562,18 @@ int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, f
 
 // ---- single-op surface ----
 int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes) {
-    (void)D; (void)H; (void)W;
-    *bytes = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096 +
-             align_up((size_t)28 * round_up(cin, 32) * round_up(cout, 32) * 2);
+    size_t b = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096 +
+               align_up((size_t)28 * round_up(cin, 32) * round_up(cout, 32) * 2);
+    if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {
+        ConvGeom g;   // MFMA wgrad slabs: stride-1 geometry has the most tiles
+        g.Cin = cin; g.Cout = cout; g.D = g.Do = D; g.H = g.Ho = H; g.W = g.Wo = W; g.ks = 3; g.stride = 1;
+        size_t w = mfma_wgrad_scratch_bytes(g);
+        if (w > b) b = w;
+        g.stride = 2; g.Do = (D - 1) / 2 + 1; g.Ho = (H - 1) / 2 + 1; g.Wo = (W - 1) / 2 + 1;
+        w = mfma_wgrad_scratch_bytes(g);
+        if (w > b) b = w;
+    }
+    *bytes = b;
     return 0;
 }
 
@@ -603,10 +633,12 @@ int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w,
 int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout, int D,
                               int H, int W, int ks, int stride, void* scratch, void* stream) {
     OP_TRY({
-        (void)impl; (void)scratch;
         ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
         SrcDesc sd; sd.ptr = x; sd.C = cin;
-        launch_conv_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, (hipStream_t)stream);
+        if (impl == UNET_IMPL_AUTO && mfma_wgrad_supported(dtype, g, &sd, 1))
+            launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
+        else
+            launch_conv_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, (hipStream_t)stream);
     })
 }
 int unet_op_convt_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D, int H,

@@ -120,6 +120,11 @@ void launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const
                           float* stats_partial, hipStream_t s);
 // number of thread blocks (= statistics partials) launch_mfma_conv_fwd uses for this geometry
 int mfma_conv_blocks(const ConvGeom& g);
+// wgrad (+ bias grad) of a 3x3x3 conv, stride 1 or 2; dw/db fp32 torch layout, accumulated (+=); db may be nullptr
+bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
+void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
+                            hipStream_t s);
 // dgrad of a stride-1 3x3x3 conv (g = forward geometry); same support condition as the forward kernel
 void launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
 
