@@ -134,6 +134,12 @@ struct unet_plan {
                 if (b > wmax) wmax = b;
             }
         }
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
+            size_t b = wgrad_direct_scratch_bytes(op_geom_of(op), op.kind == OP_CONVT);
+            if (b > wmax) wmax = b;
+        }
         wgrad_off = take(wmax ? wmax : 256);
         ws_bytes = off;
     }
@@ -301,11 +307,11 @@ struct Exec {
                         if (p.wgrad_mfma[i])
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
                         else
-                            launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
+                            launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
                         if (any && p.use_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
-                        launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], s);
+                        launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
                         if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     }
                     if (any) mark(op);
@@ -638,7 +644,7 @@ int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy
         if (impl == UNET_IMPL_AUTO && mfma_wgrad_supported(dtype, g, &sd, 1))
             launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
         else
-            launch_conv_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, (hipStream_t)stream);
+            launch_conv_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);
     })
 }
 int unet_op_convt_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D, int H,
@@ -671,7 +677,7 @@ int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy,
         (void)impl; (void)scratch;
         ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
         SrcDesc sd; sd.ptr = x; sd.C = cin;
-        launch_convt_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, (hipStream_t)stream);
+        launch_convt_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);
     })
 }
 int unet_op_pack_ndhwc(int dtype, const float* x, void* y, int C, int64_t S, void* stream) {

@@ -48,15 +48,17 @@ void launch_conv_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, in
                             void* out, float* out_ncdhw, hipStream_t s);
 void launch_conv_dgrad_direct(int dtype, const ConvGeom& g, const void* dy, const float* w_dgrad, const DstGrad* dst, int ndst,
                               hipStream_t s);
-// dw/db in torch layout, accumulated (+=)
+// dw/db in torch layout, accumulated (+=).  scratch (wgrad_direct_scratch_bytes, may be nullptr) lets the kernel split
+// the voxel range over more blocks (partial slabs summed in a fixed order)
+size_t wgrad_direct_scratch_bytes(const ConvGeom& g, int transposed);
 void launch_conv_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
-                              hipStream_t s);
+                              void* scratch, hipStream_t s);
 void launch_convt_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias,
                              void* out, hipStream_t s);
 void launch_convt_dgrad_direct(int dtype, const ConvGeom& g, const void* dy, const float* w_dgrad, const DstGrad* dst, int ndst,
                                hipStream_t s);
 void launch_convt_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
-                               hipStream_t s);
+                               void* scratch, hipStream_t s);
 
 // ---- normalisation ----
 // number of partial blocks the statistics kernels use for S voxels (plan-time constant)

@@ -212,6 +212,8 @@ struct WgradArgs {
     float* dw;
     int transposed;  // 0 conv, 1 conv_trans (ks2 stride2)
     int CW;          // threads along cout (power of two <= 256)
+    float* slab;     // nullptr: add into dw directly; else partial sums slab[blockIdx.z][idx] (split over voxel rows)
+    int64_t total;   // k3 * Cin * Cout
 };
 
 template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(WgradArgs a) {
@@ -231,7 +233,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(Wgra
         if (!a.transposed) {
             int pad = (g.ks - 1) / 2;
             int kz = tap / (g.ks * g.ks), ky = (tap / g.ks) % g.ks, kx = tap % g.ks;
-            for (int row = lane; row < g.Do * g.Ho; row += NV) {
+            const int rows = g.Do * g.Ho, rps = (rows + gridDim.z - 1) / gridDim.z;
+            const int r0 = blockIdx.z * rps, r1 = r0 + rps < rows ? r0 + rps : rows;
+            for (int row = r0 + lane; row < r1; row += NV) {
                 int z = row / g.Ho, y = row % g.Ho;
                 int iz = z * g.stride + kz - pad, iy = y * g.stride + ky - pad;
                 if (iz < 0 || iz >= g.D || iy < 0 || iy >= g.H) continue;
@@ -246,7 +250,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(Wgra
             }
         } else {
             int tz = tap >> 2, ty = (tap >> 1) & 1, tx = tap & 1;
-            for (int row = lane; row < g.D * g.H; row += NV) {
+            const int rows = g.D * g.H, rps = (rows + gridDim.z - 1) / gridDim.z;
+            const int r0 = blockIdx.z * rps, r1 = r0 + rps < rows ? r0 + rps : rows;
+            for (int row = r0 + lane; row < r1; row += NV) {
                 int z = row / g.H, y = row % g.H;
                 int64_t ibase = (int64_t)row * g.W, obase = ((int64_t)(2 * z + tz) * g.Ho + (2 * y + ty)) * g.Wo + tx;
                 float racc = 0.f;
@@ -262,20 +268,31 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(Wgra
         double s = 0.0;
         for (int l = 0; l < NV; ++l) s += red[l * CW + (threadIdx.x % CW)];
         int64_t idx = a.transposed ? ((int64_t)ci * g.Cout + co) * 8 + tap : ((int64_t)co * g.Cin + ci) * k3 + tap;
-        a.dw[idx] += (float)s;
+        if (a.slab) a.slab[(int64_t)blockIdx.z * a.total + idx] = (float)s;
+        else a.dw[idx] += (float)s;
     }
 }
 
+// out[i] += sum_k slab[k][i]   (fixed order: deterministic)
+__global__ void k_slab_reduce(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * n + i];
+    out[i] += (float)s;
+}
+
 // bias grad: db[c] += sum over voxels of dy[v][c]; one block per channel
-template <typename T> __global__ void __launch_bounds__(256) k_bias_grad(const T* __restrict__ dy, int C, int64_t S, float* db) {
+template <typename T> __global__ void __launch_bounds__(256) k_bias_grad(const T* __restrict__ dy, int C, int64_t S, float* db, float* slab) {
     __shared__ double red[256];
     int c = blockIdx.x;
     double acc = 0.0;
-    for (int64_t v0 = threadIdx.x; v0 < S; v0 += 256 * 64) {
+    const int64_t per = (S + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = s0 + per < S ? s0 + per : S;
+    for (int64_t v0 = s0 + threadIdx.x; v0 < s1; v0 += 256 * 64) {
         float r = 0.f;
         for (int k = 0; k < 64; ++k) {
             int64_t v = v0 + (int64_t)k * 256;
-            if (v < S) r += ld<T>(dy, v * C + c);
+            if (v < s1) r += ld<T>(dy, v * C + c);
         }
         acc += (double)r;
     }
@@ -285,11 +302,33 @@ template <typename T> __global__ void __launch_bounds__(256) k_bias_grad(const T
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) db[c] += (float)red[0];
+    if (threadIdx.x == 0) {
+        if (slab) slab[(int64_t)blockIdx.y * C + c] = (float)red[0];
+        else db[c] += (float)red[0];
+    }
+}
+
+static int wgrad_direct_split(const ConvGeom& g, int transposed) {
+    int CW = 1;
+    while (CW < g.Cout && CW < 256) CW <<= 1;
+    int k3 = transposed ? 8 : g.ks * g.ks * g.ks;
+    int64_t blocks = (int64_t)k3 * g.Cin * ((g.Cout + CW - 1) / CW);
+    int rows = transposed ? g.D * g.H : g.Do * g.Ho;
+    int NV = 256 / CW;
+    int64_t want = 2048 / blocks;
+    int maxs = (rows + NV - 1) / NV;      // at least one row per voxel lane
+    if (want > maxs) want = maxs;
+    return want < 1 ? 1 : (int)want;
+}
+static int bias_split(int64_t S) { int64_t n = S / 16384; return n < 1 ? 1 : (n > 256 ? 256 : (int)n); }
+size_t wgrad_direct_scratch_bytes(const ConvGeom& g, int transposed) {
+    int k3 = transposed ? 8 : g.ks * g.ks * g.ks;
+    int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+    return ((size_t)wgrad_direct_split(g, transposed) * k3 * g.Cin * g.Cout + (size_t)bias_split(So) * g.Cout) * 4 + 256;
 }
 
 static void launch_wgrad_common(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
-                                int transposed, hipStream_t s) {
+                                int transposed, void* scratch, hipStream_t s) {
     WgradArgs a;
     a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
     a.dy = dy; a.dw = dw; a.transposed = transposed;
@@ -297,20 +336,27 @@ static void launch_wgrad_common(int dtype, const ConvGeom& g, const SrcDesc* src
     while (CW < g.Cout && CW < 256) CW <<= 1;
     a.CW = CW;
     int k3 = transposed ? 8 : g.ks * g.ks * g.ks;
-    dim3 grid((unsigned)(k3 * g.Cin), (unsigned)((g.Cout + CW - 1) / CW));
+    int nsplit = scratch ? wgrad_direct_split(g, transposed) : 1;
+    a.total = (int64_t)k3 * g.Cin * g.Cout;
+    a.slab = nsplit > 1 ? (float*)scratch : nullptr;
+    dim3 grid((unsigned)(k3 * g.Cin), (unsigned)((g.Cout + CW - 1) / CW), (unsigned)nsplit);
     UNET_DISPATCH(dtype, (k_wgrad_direct<T><<<grid, 256, 0, s>>>(a)));
+    if (nsplit > 1) k_slab_reduce<<<cdiv64(a.total, 256), 256, 0, s>>>(a.slab, nsplit, a.total, dw);
     if (db) {
         int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
-        UNET_DISPATCH(dtype, (k_bias_grad<T><<<g.Cout, 256, 0, s>>>((const T*)dy, g.Cout, So, db)));
+        int bs = scratch ? bias_split(So) : 1;
+        float* bslab = bs > 1 ? (float*)scratch + (size_t)nsplit * a.total : nullptr;
+        UNET_DISPATCH(dtype, (k_bias_grad<T><<<dim3(g.Cout, bs), 256, 0, s>>>((const T*)dy, g.Cout, So, db, bslab)));
+        if (bs > 1) k_slab_reduce<<<cdiv64(g.Cout, 256), 256, 0, s>>>(bslab, bs, g.Cout, db);
     }
 }
 void launch_conv_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
-                              hipStream_t s) {
-    launch_wgrad_common(dtype, g, src, nsrc, dy, dw, db, 0, s);
+                              void* scratch, hipStream_t s) {
+    launch_wgrad_common(dtype, g, src, nsrc, dy, dw, db, 0, scratch, s);
 }
 void launch_convt_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
-                               hipStream_t s) {
-    launch_wgrad_common(dtype, g, src, nsrc, dy, dw, db, 1, s);
+                               void* scratch, hipStream_t s) {
+    launch_wgrad_common(dtype, g, src, nsrc, dy, dw, db, 1, scratch, s);
 }
 
 // ------------------------------------------------------------------------------------------------
