@@ -389,9 +389,64 @@ __global__ void __launch_bounds__(256) k_loss_partial(const float* __restrict__ 
     __syncthreads();
     for (int i = threadIdx.x; i < np; i += 256) partial[(int64_t)blockIdx.x * np + i] = sh[i];
 }
+// Same partials with per-thread register accumulators and a fixed-order block reduction: bit-exact from run to run.
+// Used whenever the (merged) class count fits OCMAX; the LDS-atomic kernel above only serves larger class counts.
+template <int OCMAX>
+__global__ void __launch_bounds__(256) k_loss_partial_reg(const float* __restrict__ logits, const int64_t* __restrict__ target, int C,
+                                                          int64_t S, int k, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int oc = k ? C - k + 1 : C, np = 3 + 2 * oc;
+    float ce = 0.f, mse = 0.f, nv = 0.f, inter[OCMAX], card[OCMAX];
+#pragma unroll
+    for (int c = 0; c < OCMAX; ++c) { inter[c] = 0.f; card[c] = 0.f; }
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < S; v += (int64_t)gridDim.x * 256) {
+        int64_t t = target[v];
+        if (!(t < C)) continue;
+        int tt = k ? (int)(t - k + 1 > 0 ? t - k + 1 : 0) : (int)t;
+        VoxelLogits L = make_vl(logits, S, v, k);
+        float lg[OCMAX], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c) { lg[c] = c < oc ? L.get(c) : -INFINITY; mx = fmaxf(mx, lg[c]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c) { lg[c] = c < oc ? expf(lg[c] - mx) : 0.f; sum += lg[c]; }
+        float inv = 1.f / sum, psq = 0.f, pt = 0.f, lt = 0.f;
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c) {
+            if (c < oc) {
+                float p = clamp_p(lg[c] * inv);
+                psq = fmaf(p, p, psq);
+                bool hit = c == tt;
+                if (hit) { pt = p; lt = L.get(c); inter[c] += p; }
+                card[c] += p + (hit ? 1.f : 0.f);
+            }
+        }
+        ce += -(lt - mx - logf(sum));
+        mse += psq - 2.f * pt + 1.f;
+        nv += 1.f;
+    }
+    for (int i = 0; i < np; ++i) {
+        float val = i == 0 ? ce : i == 1 ? mse : i == 2 ? nv : 0.f;
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c) {
+            if (c < oc && i == 3 + c) val = inter[c];
+            if (c < oc && i == 3 + oc + c) val = card[c];
+        }
+        red[threadIdx.x] = val;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * np + i] = red[0];
+        __syncthreads();
+    }
+}
 void launch_loss_partial(const float* logits, const int64_t* target, int C, int64_t S, int collapse, float* partial, hipStream_t s) {
     int oc = collapse ? C - collapse + 1 : C;
-    k_loss_partial<<<loss_blocks(S), 256, (3 + 2 * oc) * sizeof(float), s>>>(logits, target, C, S, collapse, partial);
+    if (oc <= 8) k_loss_partial_reg<8><<<loss_blocks(S), 256, 0, s>>>(logits, target, C, S, collapse, partial);
+    else if (oc <= 32) k_loss_partial_reg<32><<<loss_blocks(S), 256, 0, s>>>(logits, target, C, S, collapse, partial);
+    else k_loss_partial<<<loss_blocks(S), 256, (3 + 2 * oc) * sizeof(float), s>>>(logits, target, C, S, collapse, partial);
 }
 
 // level_out: [0] ce [1] dice [2] mse [3] n  [4 .. 4+oc) inter  [4+oc .. 4+2oc) card
