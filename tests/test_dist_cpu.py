@@ -1,0 +1,119 @@
+"""CPU, world_size 2 over gloo: the data-parallel step of unet-studio_amd/train.py (static b % world sharding of the
+batch_size micro-steps, ONE sum all-reduce of the flat gradient buffer, identical update on every rank) gives
+the same parameters as the single-rank step -- the equivalence the reference relies on when it sums replica
+gradients before the update (train.cpp:604-606,756-766).  The compute stand-in is the ATen oracle: no GPU here."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import unet_studio_amd as U
+from oracle import aten_ref as A
+
+ARCH = ("conv4,ks3,stride1+norm,leaky_relu\nconv8,ks3,stride2+norm,leaky_relu+conv_trans4,ks2,stride2\n"
+        "conv4,ks3,stride1+norm,leaky_relu+conv3,ks1,stride1")
+
+
+class _CpuOptimizer:
+    def __init__(self, model, lr):
+        self.model, self.param_groups = model, [{"lr": lr}, {"lr": lr}]
+        self.opt = model.ref.create_optimizer(lr)
+
+    def step(self, grad_scale=1.0, clip_norm=12.0):
+        m = self.model
+        off = 0
+        for p in m.ref.parameters():       # flat buffer -> .grad
+            n = p.numel()
+            p.grad = m.flat_grads[off:off + n].view_as(p).clone()
+            off += n
+        A.train_step_epilogue(m.ref, self.opt, 1.0 / grad_scale, lr=self.param_groups[0]["lr"])
+        m.flat_grads.zero_()
+
+
+class CpuStandInModel:
+    """same host surface as unet3d.UNet3d (flat_grads, forward_backward, optimizer.step) on the ATen oracle"""
+
+    def __init__(self):
+        torch.manual_seed(0)
+        self.ref = A.UNet3dRef(1, 3, ARCH)
+        self.ref.train()
+        self.flat_grads = torch.zeros(sum(p.numel() for p in self.ref.parameters()))
+        self.optimizer = None
+        import threading
+        self.error_mutex, self.training_errors = threading.Lock(), []
+
+    def device(self):
+        return torch.device("cpu")
+
+    def train(self):
+        return self
+
+    def create_optimizer(self, lr):
+        self.optimizer = _CpuOptimizer(self, lr)
+
+    def forward_backward(self, x, t, ce=True, dice=True, mse=True):
+        for p in self.ref.parameters():
+            p.grad = None
+        outs = self.ref(x)
+        loss, st = A.deep_supervision_loss(outs, t, 3, ce, dice, mse)
+        loss.backward()
+        self.flat_grads += torch.cat([p.grad.flatten() for p in self.ref.parameters()])
+        return torch.stack([loss.detach(), *st])
+
+    def flat_params(self):
+        return torch.cat([p.detach().flatten() for p in self.ref.parameters()])
+
+
+def _source(i):
+    x, t = A.synthetic_sample(1, 3, (8, 8, 8), i)
+    return x, t
+
+
+def _run(rank, world, port, steps, batch, out):
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = CpuStandInModel()
+    tr = U.Trainer(m, U.TrainingParam(batch_size=batch, epoch=100, learning_rate=0.05), _source, rank, world)
+    stats = []
+    for _ in range(steps):
+        stats.append(tr.step().clone())
+    out[rank] = (m.flat_params().numpy(), torch.stack(stats).numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_equals_single_rank():
+    steps, batch = 3, 4
+    single = {}
+    _run(0, 1, 0, steps, batch, single)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run, args=(2, _free_port(), steps, batch, out), nprocs=2, join=True)
+    p0, s0 = out[0]
+    p1, s1 = out[1]
+    assert np.array_equal(p0, p1), "ranks diverged: the update is not identical on every rank"
+    ref, sref = single[0]
+    assert np.allclose(p0, ref, rtol=1e-5, atol=1e-6)
+    assert np.allclose(s0, sref, rtol=1e-5, atol=1e-6)      # summed loss statistics, train.cpp:732-741
+    assert np.allclose(s0, s1)
+
+
+def test_lr_schedule_matches_reference():
+    tr = U.Trainer(CpuStandInModel(), U.TrainingParam(batch_size=1, epoch=1000, learning_rate=0.001), _source)
+    for e in (0, 1, 500, 999):
+        assert abs(tr.lr_at(e) - 0.001 * (1.0 - e / 1000.0) ** 0.9) < 1e-12   # train.cpp:566
