@@ -100,7 +100,9 @@ def test_conv3d_ops(case, dt, impl):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("case", [(16, 16, (4, 5, 6)), (7, 3, (3, 4, 5)), (32, 16, (4, 4, 8))])
+@pytest.mark.parametrize("case", [(16, 16, (4, 5, 6)), (7, 3, (3, 4, 5)), (32, 16, (4, 4, 8)),
+                                  # MFMA conv_trans (Cin % 32 == 0): every tile configuration, ragged edges
+                                  (64, 32, (3, 5, 19)), (32, 32, (4, 4, 4)), (128, 64, (2, 3, 2)), (32, 48, (5, 9, 7))])
 def test_convt_ops(case, dt):
     cin, cout, (D, H, W) = case
     l = O.lib()

@@ -1,7 +1,21 @@
 #!/bin/bash
 # Builds libunet_hip.so for gfx950 in-tree (next to the Python package).  No GPU needed: hipcc cross-compiles.
+# Objects are compiled in parallel (one hipcc per source) and only when the source or a header is newer.
 set -e
 cd "$(dirname "$0")"
-SRCS="graph.cpp engine.cpp kernels_direct.hip kernels_elem.hip kernels_mfma.hip"
-hipcc -O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -Wno-unused-result -o ../libunet_hip.so $SRCS
+SRCS="graph.cpp engine.cpp kernels_direct.hip kernels_elem.hip kernels_mfma_conv.hip kernels_mfma_wgrad.hip"
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-result"
+mkdir -p build
+newest_hdr=$(ls -t *.h *.hpp ../../include/*.h | head -1)
+todo=""
+for f in $SRCS; do
+    o=build/${f%.*}.o
+    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then todo="$todo $f"; fi
+done
+if [ -n "$todo" ]; then
+    echo $todo | tr ' ' '\n' | xargs -P 6 -I{} sh -c 'f={}; hipcc '"$FLAGS"' -c "$f" -o build/${f%.*}.o'
+fi
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS build/${f%.*}.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libunet_hip.so $OBJS
 echo "built $(cd .. && pwd)/libunet_hip.so"

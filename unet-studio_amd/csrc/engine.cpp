@@ -50,7 +50,8 @@ struct unet_plan {
     std::vector<size_t> n_stat, n_coef;      // per norm: 4C / 3C floats
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
     std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
-    std::vector<char> use_mfma;              // per op
+    std::vector<char> use_mfma;              // per op: forward runs on the MFMA kernel
+    std::vector<char> dgrad_mfma;            // per op: dgrad runs on the MFMA kernel
     std::vector<char> wgrad_mfma;            // per op: wgrad runs on the MFMA kernel
     size_t wgrad_off = 0;
     size_t partial_off = 0, partial_bytes = 0;
@@ -95,6 +96,7 @@ struct unet_plan {
         w_fwd.assign(g.ops.size(), SIZE_MAX); w_dgrad.assign(g.ops.size(), SIZE_MAX);
         wm_fwd.assign(g.ops.size(), SIZE_MAX); wm_dgrad.assign(g.ops.size(), SIZE_MAX);
         use_mfma.assign(g.ops.size(), 0);
+        dgrad_mfma.assign(g.ops.size(), 0);
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
@@ -108,12 +110,24 @@ struct unet_plan {
                 if (mfma_conv_fwd_supported(dtype, cg, sd, op.nsrc)) {
                     use_mfma[i] = 1;
                     wm_fwd[i] = take(mfma_conv_w_bytes(cg));
-                    ConvGeom t = cg; t.Cin = cg.Cout; t.Cout = cg.Cin;
-                    wm_dgrad[i] = take(mfma_conv_w_bytes(t));
                     if (g.tensors[op.dst].norm >= 0) {
                         size_t pb = (size_t)mfma_conv_blocks(cg) * op.cout * 2 * 4;
                         if (pb > pmax) pmax = pb;
                     }
+                }
+                if (mfma_conv_dgrad_supported(dtype, cg, sd, op.nsrc)) {
+                    dgrad_mfma[i] = 1;
+                    wm_dgrad[i] = take(mfma_conv_dgrad_w_bytes(cg));
+                }
+            }
+            if (op.kind == OP_CONVT && impl == UNET_IMPL_AUTO) {
+                ConvGeom cg = op_geom_of(op);
+                SrcDesc sd[2];
+                for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
+                if (mfma_convt_supported(dtype, cg, sd, op.nsrc)) {
+                    use_mfma[i] = 1; dgrad_mfma[i] = 1;
+                    wm_fwd[i] = take(mfma_convt_w_bytes(cg));
+                    wm_dgrad[i] = take(mfma_convt_dgrad_w_bytes(cg));
                 }
             }
         }
@@ -192,7 +206,10 @@ struct Exec {
                     float* wf = (float*)(ws + p.w_fwd[i]);
                     float* wd = (float*)(ws + p.w_dgrad[i]);
                     if (op.kind == OP_CONV && p.use_mfma[i]) {
-                        launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i], mode == 1 ? ws + p.wm_dgrad[i] : nullptr, cg, s);
+                        launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i],
+                                                (mode == 1 && p.dgrad_mfma[i]) ? ws + p.wm_dgrad[i] : nullptr, cg, s);
+                        if (mode == 1 && !p.dgrad_mfma[i])
+                            launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         const Tensor& T = g.tensors[op.dst];
                         bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
                         launch_mfma_conv_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst),
@@ -202,6 +219,9 @@ struct Exec {
                         launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
                                                op.out_level >= 0 ? outs[op.out_level] : nullptr, s);
+                    } else if (p.use_mfma[i]) {
+                        launch_mfma_pack_convt_w(params[op.weight], ws + p.wm_fwd[i], mode == 1 ? ws + p.wm_dgrad[i] : nullptr, cg, s);
+                        launch_mfma_convt_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst), s);
                     } else {
                         launch_pack_convt_w(params[op.weight], wf, wd, op.cin, op.cout, s);
                         launch_convt_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst), s);
@@ -308,11 +328,12 @@ struct Exec {
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
                         else
                             launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
-                        if (any && p.use_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        if (any && p.dgrad_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
                         launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
-                        if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
+                        if (any && p.dgrad_mfma[i]) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        else if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     }
                     if (any) mark(op);
                     break;
@@ -569,7 +590,7 @@ int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, f
 // ---- single-op surface ----
 int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes) {
     size_t b = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096 +
-               align_up((size_t)28 * round_up(cin, 32) * round_up(cout, 32) * 2);
+               align_up((size_t)160 * round_up(cin, 32) * round_up(cout, 32));   // largest MFMA filter pack: stride-2 dgrad, 128 B per Cin*Cout
     if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {
         ConvGeom g;   // MFMA wgrad slabs: stride-1 geometry has the most tiles
         g.Cin = cin; g.Cout = cout; g.D = g.Do = D; g.H = g.Ho = H; g.W = g.Wo = W; g.ks = 3; g.stride = 1;
@@ -626,7 +647,7 @@ int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w,
         float *wf, *wd;
         DstGrad d; d.ptr = dx; d.C = cin; d.accumulate = 0;
         SrcDesc sd; sd.C = cin;
-        if (impl == UNET_IMPL_AUTO && mfma_conv_fwd_supported(dtype, g, &sd, 1)) {
+        if (impl == UNET_IMPL_AUTO && mfma_conv_dgrad_supported(dtype, g, &sd, 1)) {
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_conv_w(w, nullptr, wm, g, s);
             launch_mfma_conv_dgrad(g, dy, wm, &d, 1, s);
@@ -650,25 +671,36 @@ int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy
 int unet_op_convt_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D, int H,
                       int W, void* scratch, void* stream) {
     OP_TRY({
-        (void)impl;
         hipStream_t s = (hipStream_t)stream;
         ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
         float *wf, *wd;
-        op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
         SrcDesc sd; sd.ptr = x; sd.C = cin;
-        launch_convt_fwd_direct(dtype, g, &sd, 1, wf, b, y, s);
+        if (impl == UNET_IMPL_AUTO && mfma_convt_supported(dtype, g, &sd, 1)) {
+            void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
+            launch_mfma_pack_convt_w(w, wm, nullptr, g, s);
+            launch_mfma_convt_fwd(g, &sd, 1, wm, b, y, s);
+        } else {
+            op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
+            launch_convt_fwd_direct(dtype, g, &sd, 1, wf, b, y, s);
+        }
     })
 }
 int unet_op_convt_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H, int W,
                            void* scratch, void* stream) {
     OP_TRY({
-        (void)impl;
         hipStream_t s = (hipStream_t)stream;
         ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
         float *wf, *wd;
-        op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
         DstGrad d; d.ptr = dx; d.C = cin; d.accumulate = 0;
-        launch_convt_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
+        SrcDesc sd; sd.C = cin;
+        if (impl == UNET_IMPL_AUTO && mfma_convt_supported(dtype, g, &sd, 1)) {
+            void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
+            launch_mfma_pack_convt_w(w, nullptr, wm, g, s);
+            launch_mfma_convt_dgrad(g, dy, wm, &d, 1, s);
+        } else {
+            op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
+            launch_convt_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
+        }
     })
 }
 int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout, int D, int H,

@@ -127,7 +127,16 @@ bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int 
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s);
-// dgrad of a stride-1 3x3x3 conv (g = forward geometry); same support condition as the forward kernel
+// dgrad of a 3x3x3 conv, stride 1 or 2 (g = forward geometry)
+bool mfma_conv_dgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t mfma_conv_dgrad_w_bytes(const ConvGeom& g);
 void launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
+// ConvTranspose3d 2x2x2 stride 2: forward (1x1 GEMM + depth-to-space scatter) and dgrad (2x2x2 stride-2 conv of dL/dy)
+bool mfma_convt_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t mfma_convt_w_bytes(const ConvGeom& g);
+size_t mfma_convt_dgrad_w_bytes(const ConvGeom& g);
+void launch_mfma_pack_convt_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
+void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s);
+void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
 
 }  // namespace unet

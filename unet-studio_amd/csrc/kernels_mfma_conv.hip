@@ -1,0 +1,436 @@
+// MFMA implicit-GEMM conv family for gfx950 (bf16 storage, fp32 accumulate).
+//
+// One kernel template covers every dense contraction of the path except wgrad:
+//     D[row][voxel] += W[row][k] * X[k][voxel],   k = (tap, channel),   v_mfma_f32_16x16x32_bf16
+//   kind                         S  KD PAD SC   rows            taps   reads        reference
+//   conv 3x3x3 s1 forward        1  3  1   -    Cout            27     input        unet.cpp:59-72
+//   conv 3x3x3 s1 dgrad          1  3  1   -    Cin             27     dL/dy        (flipped, transposed filter)
+//   conv 3x3x3 s2 forward        2  3  1   -    Cout            27     input
+//   conv 3x3x3 s2 dgrad          1  2  0   yes  8 parities*Cin  8      dL/dy        (zero-filled parity filter)
+//   conv_trans 2x2x2 s2 forward  1  1  0   yes  8 taps*Cout     1      input        unet.cpp:46-57
+//   conv_trans 2x2x2 s2 dgrad    2  2  0   -    Cin             8      dL/dy
+//   * A operand  = filter tile, pre-packed in fragment order (one 16-B load per lane, L2-resident).
+//   * B operand  = input patches, ds_read_b128 from an LDS halo tile [HZ][HY][HX][CK channels] staged once per
+//                  CK-channel chunk and re-used by all taps.
+//   * the producer's norm + activation (scale/shift per channel, then relu/leaky/elu) is applied while staging,
+//     zero padding after it (padding pads the ACTIVATED tensor); a channel concat {skip, x} (unet.cpp:181) is just
+//     a second source pointer.
+//   * epilogue: + bias, round to bf16, 8-B stores (4 consecutive channels per lane); optional per-block
+//     {sum, sum of squares} per channel for the following norm; optional accumulate / two destinations (dgrad
+//     of a concat); SC = depth-to-space scatter: row block `tap` goes to output voxel 2*v + tap.
+#include "mfma_util.h"
+
+namespace unet {
+
+struct MfmaConvArgs {
+    ConvGeom g;          // GEMM view: Cin = contraction channels, Cout = rows; D,H,W = volume read; Do,Ho,Wo = grid the tiles cover
+    SrcDesc src[2];
+    int nsrc;
+    const void* w;       // packed filter
+    const float* bias;   // nullptr: none (indexed by destination channel)
+    void* out[2];        // channels-last bf16 destinations (split at outC[0] channels)
+    int outC[2];
+    int out_acc[2];
+    int nout;
+    float* stats;        // [nblk][Cout][2] or nullptr
+    int tiles_x, tiles_y, tiles_z;
+    int sc_C;            // SC: destination channels per tap (rows = 8 * sc_C)
+    int oD, oH, oW;      // destination volume
+};
+
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
+__global__ void __launch_bounds__(256) k_mfma_conv(MfmaConvArgs a) {
+    constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD, NVOX = HZ * HY * HX;
+    constexpr int G = CK / 8;                    // 16-B channel groups per voxel
+    constexpr int VS = CK == 32 ? 96 : 32;       // LDS bytes per voxel (96: conflict-free ds_read_b128 for 64-B payloads)
+    constexpr int TXM = BX < 16 ? BX : 16;       // m-tile = TYM rows x TXM columns of one z-plane
+    constexpr int TYM = 16 / TXM;
+    constexpr int MT = BZ * BY * BX / 16, MTW = MT / 4;
+    constexpr int T = KD * KD * KD;
+    constexpr int KSTEPS = CK == 32 ? T : (T + 1) / 2;
+    static_assert(MT % 4 == 0 && MTW >= 1, "tile must give every wave at least one m-tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
+    const int nblk = a.tiles_x * a.tiles_y * a.tiles_z;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
+    const int nt0 = blockIdx.y * NT, NTT = g.Cout / 16;
+
+    // this lane's voxel of each of the wave's m-tiles: tile-local coordinates and LDS byte offset
+    int mz[MTW], my[MTW], mx[MTW], mbase[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        int mt = wave * MTW + i;
+        constexpr int RG = BY / TYM;             // row groups per z-plane
+        mz[i] = mt / RG; my[i] = (mt % RG) * TYM + (j / TXM); mx[i] = j % TXM;
+        mbase[i] = ((mz[i] * S * HY + my[i] * S) * HX + mx[i] * S) * VS + (CK == 32 ? gq : (gq & 1)) * 16;
+    }
+
+    f32x4 acc[MTW][NT];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int C0 = a.src[0].C;
+    const int lg = tid % G;                      // this thread's channel group inside the chunk (256 % G == 0)
+    const int nchunk = g.Cin / CK;
+    const bf16x8* wp = (const bf16x8*)a.w;
+    const int iz0 = z0 * S - PAD, iy0 = y0 * S - PAD, ix0 = x0 * S - PAD;
+
+    for (int q = 0; q < nchunk; ++q) {
+        // ---- stage the halo tile of channels [q*CK, q*CK+CK) ----
+        {
+            int c = q * CK + lg * 8;
+            int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
+            const SrcDesc& sd = a.src[s];
+            int cl = c - (s ? C0 : 0);
+            const char* base = (const char*)sd.ptr + (size_t)cl * 2;
+            float sc[8], sh[8];
+            const bool xf = sd.scale != nullptr;
+            if (xf) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sc[e] = sd.scale[cl + e]; sh[e] = sd.shift[cl + e]; }
+            }
+            const int act = sd.act;
+            constexpr int UNITS = NVOX * G, ITERS = (UNITS + 255) / 256;
+            __syncthreads();                      // previous chunk's reads are done
+#pragma unroll 4
+            for (int it = 0; it < ITERS; ++it) {
+                int u = tid + it * 256;
+                if (u < UNITS) {
+                    int hv = u / G;
+                    int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
+                    int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                        size_t vox = ((size_t)gz * g.H + gy) * g.W + gx;
+                        v = transform8(*(const uint4*)(base + vox * (size_t)sd.C * 2), xf, sc, sh, act);
+                    }
+                    *(uint4*)(smem + hv * VS + lg * 16) = v;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- taps x MFMA ----
+        const bf16x8* wq = wp + ((size_t)q * KSTEPS * NTT + nt0) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            bf16x8 wf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wf[n] = wq[((size_t)ks * NTT + n) * 64];
+            int toff;
+            if (CK == 32) {
+                toff = (((ks / (KD * KD)) * HY + (ks / KD) % KD) * HX + ks % KD) * VS;
+            } else {
+                const int t0 = 2 * ks, t1 = 2 * ks + 1 < T ? 2 * ks + 1 : 2 * ks;   // a tap past the last one has a zero filter
+                const int o0 = (((t0 / (KD * KD)) * HY + (t0 / KD) % KD) * HX + t0 % KD) * VS;
+                const int o1 = (((t1 / (KD * KD)) * HY + (t1 / KD) % KD) * HX + t1 % KD) * VS;
+                toff = (lane & 32) ? o1 : o0;
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                bf16x8 xb = *(const bf16x8*)(smem + mbase[i] + toff);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xb, acc[i][n], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        int c = (nt0 + n) * 16 + gq * 4;          // first of this lane's 4 rows
+        int tz = 0, ty = 0, tx = 0;
+        if (SC) { int tap = c / a.sc_C; c -= tap * a.sc_C; tz = tap >> 2; ty = (tap >> 1) & 1; tx = tap & 1; }
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = a.bias[c + r];
+        }
+        int d = (a.nout > 1 && c >= a.outC[0]) ? 1 : 0;
+        int cd = c - (d ? a.outC[0] : 0);
+        char* obase = (char*)a.out[d];
+        const int oC = a.outC[d], oacc = a.out_acc[d];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            int gz = z0 + mz[i], gy = y0 + my[i], gx = x0 + mx[i];
+            if (SC) { gz = 2 * gz + tz; gy = 2 * gy + ty; gx = 2 * gx + tx; }
+            if (gz < a.oD && gy < a.oH && gx < a.oW && obase) {
+                size_t vox = ((size_t)gz * a.oH + gy) * a.oW + gx;
+                uint2* p = (uint2*)(obase + (vox * oC + cd) * 2);
+                float v0 = acc[i][n][0] + b4[0], v1 = acc[i][n][1] + b4[1], v2 = acc[i][n][2] + b4[2], v3 = acc[i][n][3] + b4[3];
+                if (oacc) {
+                    uint2 old = *p;
+                    v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                *p = o;
+                if (!SC && a.stats) {   // statistics of the values as stored (rounded to bf16)
+                    float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
+                    s1[n][0] += r0; s1[n][1] += r1; s1[n][2] += r2; s1[n][3] += r3;
+                    s2[n][0] = fmaf(r0, r0, s2[n][0]); s2[n][1] = fmaf(r1, r1, s2[n][1]);
+                    s2[n][2] = fmaf(r2, r2, s2[n][2]); s2[n][3] = fmaf(r3, r3, s2[n][3]);
+                }
+            }
+        }
+    }
+    if (!SC && a.stats) {
+        float* red = (float*)smem;                // [wave][NT*16][2]
+        __syncthreads();                          // LDS tile no longer needed
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[n][r], v = s2[n][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+                if (j == 0) {
+                    int cl = n * 16 + gq * 4 + r;
+                    red[(wave * NT * 16 + cl) * 2 + 0] = u;
+                    red[(wave * NT * 16 + cl) * 2 + 1] = v;
+                }
+            }
+        __syncthreads();
+        if (tid < NT * 16) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
+            int c = nt0 * 16 + tid;
+            a.stats[((size_t)bid * g.Cout + c) * 2 + 0] = u;
+            a.stats[((size_t)bid * g.Cout + c) * 2 + 1] = v;
+        }
+    }
+}
+
+// ---- filter packing: fp32 torch layout -> bf16 fragments [chunk][kstep][row tile][lane][8] ----
+enum PackMode {
+    PK_CONV_FWD = 0,    // rows o = cout, k-channel i = cin, T taps:           w[(o*A + i)*T + t]              A = Cin
+    PK_CONV_DGRAD = 1,  // rows o = cin,  i = cout, 27 taps flipped:           w[(i*A + o)*27 + 26 - t]        A = Cin
+    PK_CONVT_DGRAD = 2, // rows o = cin,  i = cout, 8 taps:                    w[(o*B + i)*8 + t]              B = Cout
+    PK_CONVT_FWD = 3,   // rows o = t*B + co, i = cin, 1 tap:                  w[(i*B + co)*8 + t]             B = Cout
+    PK_CONV_S2_DGRAD = 4 // rows o = p*A + ci (p = output parity), i = cout, 8 taps k in {0,1}^3 over dy[m+k]:
+                        //   per dim  p=0: k=0 -> filter tap 1 ;  p=1: k=0 -> tap 2, k=1 -> tap 0 ; else zero     A = Cin
+};
+__global__ void k_mfma_pack(const float* __restrict__ w, __bf16* __restrict__ out, int Ci, int Co, int CK, int T, int mode, int A, int B) {
+    int KSTEPS = CK == 32 ? T : (T + 1) / 2, NTT = Co / 16;
+    int64_t total = (int64_t)(Ci / CK) * KSTEPS * NTT * 64 * 8;
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    int e = (int)(idx & 7); int64_t r = idx >> 3;
+    int lane = (int)(r & 63); r >>= 6;
+    int nt = (int)(r % NTT); r /= NTT;
+    int ks = (int)(r % KSTEPS); int q = (int)(r / KSTEPS);
+    int o = nt * 16 + (lane & 15);
+    int tap, i;
+    if (CK == 32) { tap = ks; i = q * 32 + 8 * (lane >> 4) + e; }
+    else { tap = 2 * ks + (lane >> 5); i = q * 16 + 8 * ((lane >> 4) & 1) + e; }
+    float v = 0.f;
+    if (tap < T) {
+        switch (mode) {
+            case PK_CONV_FWD: v = w[((int64_t)o * A + i) * T + tap]; break;
+            case PK_CONV_DGRAD: v = w[((int64_t)i * A + o) * 27 + (26 - tap)]; break;
+            case PK_CONVT_DGRAD: v = w[((int64_t)o * B + i) * 8 + tap]; break;
+            case PK_CONVT_FWD: { int t = o / B, co = o % B; v = w[((int64_t)i * B + co) * 8 + t]; break; }
+            case PK_CONV_S2_DGRAD: {
+                int p = o / A, ci = o % A;
+                int pk[3] = {(p >> 2) & 1, (p >> 1) & 1, p & 1}, kk[3] = {(tap >> 2) & 1, (tap >> 1) & 1, tap & 1}, ft[3];
+                bool ok = true;
+                for (int d = 0; d < 3; ++d) {
+                    if (pk[d] == 0) { ok = ok && kk[d] == 0; ft[d] = 1; }
+                    else ft[d] = kk[d] == 0 ? 2 : 0;
+                }
+                if (ok) v = w[((int64_t)i * A + ci) * 27 + (ft[0] * 9 + ft[1] * 3 + ft[2])];
+                break;
+            }
+        }
+    }
+    out[idx] = (__bf16)v;
+}
+
+static inline int pick_ck(int Ci, bool allow32) { return (allow32 && Ci % 32 == 0) ? 32 : 16; }
+static size_t pack_bytes(int Ci, int Co, int CK, int T) {
+    int KSTEPS = CK == 32 ? T : (T + 1) / 2;
+    return (size_t)(Ci / CK) * KSTEPS * (Co / 16) * 64 * 16;
+}
+static void run_pack(const float* w, void* out, int Ci, int Co, int CK, int T, int mode, int A, int B, hipStream_t s) {
+    int64_t n = (int64_t)pack_bytes(Ci, Co, CK, T) / 2;
+    k_mfma_pack<<<cdiv64(n, 256), 256, 0, s>>>(w, (__bf16*)out, Ci, Co, CK, T, mode, A, B);
+}
+
+// ---- launch plumbing ----
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
+static void launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
+    MfmaConvArgs a = a0;
+    a.tiles_x = (a.g.Wo + BX - 1) / BX; a.tiles_y = (a.g.Ho + BY - 1) / BY; a.tiles_z = (a.g.Do + BZ - 1) / BZ;
+    constexpr int VS = CK == 32 ? 96 : 32;
+    constexpr size_t lds = (size_t)((BZ - 1) * S + KD) * ((BY - 1) * S + KD) * ((BX - 1) * S + KD) * VS;
+    static_assert(lds >= 4 * NT * 16 * 2 * 4, "stats scratch must fit the tile buffer");
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_mfma_conv<S, KD, PAD, BZ, BY, BX, CK, NT, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.tiles_z), (unsigned)(a.g.Cout / (16 * NT)));
+    k_mfma_conv<S, KD, PAD, BZ, BY, BX, CK, NT, SC><<<grid, 256, lds, s>>>(a);
+}
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> static void launch_nt(const MfmaConvArgs& a, hipStream_t s) {
+    int ntt = a.g.Cout / 16;
+    if constexpr (SC) {   // scatter kinds always have ntt % 4 == 0 (rows = 8 * C, C % 16 == 0)
+        launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, true>(a, s);
+    } else {
+        if (ntt % 4 == 0) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
+        else if (ntt % 2 == 0) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
+        else launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, false>(a, s);
+    }
+}
+
+// tile shapes per kind and output-grid width (every shape keeps the LDS tile <= 64 KB)
+struct Tile { int bz, by, bx; };
+static Tile tile_s1k3(int Wo, int CK) {
+    if (Wo >= 12) return CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16};
+    return Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4};
+}
+static void launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
+    if (a.g.Wo >= 12) { if (CK == 32) launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }
+    else if (a.g.Wo > 4) { if (CK == 32) launch_nt<1, 3, 1, 4, 8, 8, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 8, 16, false>(a, s); }
+    else { if (CK == 32) launch_nt<1, 3, 1, 4, 4, 4, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 4, 4, 16, false>(a, s); }
+}
+static Tile tile_s2k3(int Wo) { return Wo >= 12 ? Tile{2, 4, 16} : (Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4}); }
+static void launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 only (halo of a stride-2 tile is 8x the output tile)
+    if (a.g.Wo >= 12) launch_nt<2, 3, 1, 2, 4, 16, 16, false>(a, s);
+    else if (a.g.Wo > 4) launch_nt<2, 3, 1, 2, 4, 8, 16, false>(a, s);
+    else launch_nt<2, 3, 1, 4, 4, 4, 16, false>(a, s);
+}
+static void launch_s2k2(const MfmaConvArgs& a, hipStream_t s) {   // conv_trans dgrad, CK 16
+    if (a.g.Wo >= 12) launch_nt<2, 2, 0, 2, 4, 16, 16, false>(a, s);
+    else if (a.g.Wo > 4) launch_nt<2, 2, 0, 4, 8, 8, 16, false>(a, s);
+    else launch_nt<2, 2, 0, 4, 4, 4, 16, false>(a, s);
+}
+static void launch_k1sc(const MfmaConvArgs& a, hipStream_t s) {   // conv_trans forward, CK 32
+    if (a.g.Wo >= 12) launch_nt<1, 1, 0, 4, 8, 16, 32, true>(a, s);
+    else if (a.g.Wo > 4) launch_nt<1, 1, 0, 4, 8, 8, 32, true>(a, s);
+    else launch_nt<1, 1, 0, 4, 4, 4, 32, true>(a, s);
+}
+static void launch_k2sc(const MfmaConvArgs& a, hipStream_t s) {   // conv s2 dgrad, CK 32
+    if (a.g.Wo >= 12) launch_nt<1, 2, 0, 4, 4, 16, 32, true>(a, s);
+    else if (a.g.Wo > 4) launch_nt<1, 2, 0, 4, 8, 8, 32, true>(a, s);
+    else launch_nt<1, 2, 0, 4, 4, 4, 32, true>(a, s);
+}
+
+static bool chan_ok(const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    if (g.Cin % 16 || g.Cout % 16) return false;
+    for (int s = 0; s < nsrc; ++s)
+        if (src[s].C % 16) return false;
+    return true;
+}
+static MfmaConvArgs base_args() {
+    MfmaConvArgs a;
+    a.nsrc = 1; a.w = nullptr; a.bias = nullptr;
+    a.out[0] = a.out[1] = nullptr; a.outC[0] = a.outC[1] = 0; a.out_acc[0] = a.out_acc[1] = 0; a.nout = 1;
+    a.stats = nullptr; a.tiles_x = a.tiles_y = a.tiles_z = 0; a.sc_C = 0; a.oD = a.oH = a.oW = 0;
+    return a;
+}
+static void set_dst(MfmaConvArgs& a, const DstGrad* dst, int ndst) {
+    for (int k = 0; k < 2; ++k) {
+        a.out[k] = k < ndst ? dst[k].ptr : nullptr;
+        a.outC[k] = k < ndst ? dst[k].C : 0;
+        a.out_acc[k] = k < ndst ? dst[k].accumulate : 0;
+    }
+    a.nout = ndst;
+}
+
+// ================= public: Conv3d 3x3x3, stride 1 or 2 =================
+bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    return dtype == 1 && g.ks == 3 && (g.stride == 1 || g.stride == 2) && chan_ok(g, src, nsrc);
+}
+static int fwd_ck(const ConvGeom& g) { return g.stride == 1 ? pick_ck(g.Cin, true) : 16; }
+size_t mfma_conv_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cin, g.Cout, fwd_ck(g), 27); }
+size_t mfma_conv_dgrad_w_bytes(const ConvGeom& g) {
+    if (g.stride == 1) return pack_bytes(g.Cout, g.Cin, pick_ck(g.Cout, true), 27);
+    return pack_bytes(g.Cout, 8 * g.Cin, pick_ck(g.Cout, true), 8);
+}
+bool mfma_conv_dgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    if (!mfma_conv_fwd_supported(dtype, g, src, nsrc)) return false;
+    return g.stride == 1 || g.Cout % 32 == 0;
+}
+void launch_mfma_pack_conv_w(const float* w, void* w_fwd, void* w_dgrad, const ConvGeom& g, hipStream_t s) {
+    if (w_fwd) run_pack(w, w_fwd, g.Cin, g.Cout, fwd_ck(g), 27, PK_CONV_FWD, g.Cin, g.Cout, s);
+    if (w_dgrad) {
+        if (g.stride == 1) run_pack(w, w_dgrad, g.Cout, g.Cin, pick_ck(g.Cout, true), 27, PK_CONV_DGRAD, g.Cin, g.Cout, s);
+        else run_pack(w, w_dgrad, g.Cout, 8 * g.Cin, 32, 8, PK_CONV_S2_DGRAD, g.Cin, g.Cout, s);
+    }
+}
+int mfma_conv_blocks(const ConvGeom& g) {
+    Tile t = g.stride == 1 ? tile_s1k3(g.Wo, fwd_ck(g)) : tile_s2k3(g.Wo);
+    return ((g.Wo + t.bx - 1) / t.bx) * ((g.Ho + t.by - 1) / t.by) * ((g.Do + t.bz - 1) / t.bz);
+}
+void launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
+                          float* stats_partial, hipStream_t s) {
+    MfmaConvArgs a = base_args();
+    a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
+    a.w = w_mfma; a.bias = bias;
+    a.out[0] = out; a.outC[0] = g.Cout;
+    a.stats = stats_partial;
+    a.oD = g.Do; a.oH = g.Ho; a.oW = g.Wo;
+    if (g.stride == 1) launch_s1k3(a, fwd_ck(g), s); else launch_s2k3(a, s);
+}
+// dgrad (g = forward geometry).  stride 1: 27-tap conv of dL/dy with the flipped filter.  stride 2: 8-tap conv of
+// dL/dy on the coarse grid producing all 8 output parities at once (rows = 8*Cin), scattered to 2*m + parity.
+void launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s) {
+    MfmaConvArgs a = base_args();
+    a.src[0].ptr = dy; a.src[0].C = g.Cout;
+    a.w = w_mfma_dgrad;
+    set_dst(a, dst, ndst);
+    a.g.Cin = g.Cout; a.g.D = g.Do; a.g.H = g.Ho; a.g.W = g.Wo; a.g.ks = 3; a.g.stride = 1;
+    a.oD = g.D; a.oH = g.H; a.oW = g.W;
+    if (g.stride == 1) {
+        a.g.Cout = g.Cin; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
+        launch_s1k3(a, pick_ck(g.Cout, true), s);
+    } else {
+        a.g.Cout = 8 * g.Cin; a.sc_C = g.Cin;
+        a.g.Do = (g.D + 1) / 2; a.g.Ho = (g.H + 1) / 2; a.g.Wo = (g.W + 1) / 2;   // coarse positions m with 2m or 2m+1 inside the volume
+        launch_k2sc(a, s);
+    }
+}
+
+// ================= public: ConvTranspose3d 2x2x2 stride 2 =================
+bool mfma_convt_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    return dtype == 1 && chan_ok(g, src, nsrc) && g.Cin % 32 == 0;
+}
+size_t mfma_convt_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cin, 8 * g.Cout, 32, 1); }
+size_t mfma_convt_dgrad_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cout, g.Cin, 16, 8); }
+void launch_mfma_pack_convt_w(const float* w, void* w_fwd, void* w_dgrad, const ConvGeom& g, hipStream_t s) {
+    if (w_fwd) run_pack(w, w_fwd, g.Cin, 8 * g.Cout, 32, 1, PK_CONVT_FWD, g.Cin, g.Cout, s);
+    if (w_dgrad) run_pack(w, w_dgrad, g.Cout, g.Cin, 16, 8, PK_CONVT_DGRAD, g.Cin, g.Cout, s);
+}
+void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s) {
+    MfmaConvArgs a = base_args();
+    a.g = g; a.g.Cout = 8 * g.Cout; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W; a.g.ks = 1; a.g.stride = 1;
+    a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
+    a.w = w_mfma; a.bias = bias;
+    a.out[0] = out; a.outC[0] = g.Cout;
+    a.sc_C = g.Cout; a.oD = g.Do; a.oH = g.Ho; a.oW = g.Wo;
+    launch_k1sc(a, s);
+}
+void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s) {
+    MfmaConvArgs a = base_args();
+    a.src[0].ptr = dy; a.src[0].C = g.Cout;
+    a.w = w_mfma_dgrad;
+    set_dst(a, dst, ndst);
+    a.g.Cin = g.Cout; a.g.Cout = g.Cin; a.g.D = g.Do; a.g.H = g.Ho; a.g.W = g.Wo; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
+    a.g.ks = 2; a.g.stride = 2;
+    a.oD = g.D; a.oH = g.H; a.oW = g.W;
+    launch_s2k2(a, s);
+}
+
+}  // namespace unet

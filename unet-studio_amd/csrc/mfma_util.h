@@ -1,0 +1,36 @@
+// Shared device helpers of the MFMA kernel files (gfx950).
+#pragma once
+#include "device_util.h"
+
+namespace unet {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)__bfloat16_as_ushort(__float2bfloat16(lo)) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(hi)) << 16);
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// blocks that share an XCD (b % 8 equal) get a contiguous range of tiles: neighbouring tiles share halos in one L2
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// 8 bf16 channels of one voxel through the consumer-side transform act(x*scale+shift)
+__device__ __forceinline__ uint4 transform8(uint4 v, bool xf, const float* sc, const float* sh, int act) {
+    if (!(xf || act)) return v;
+    unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float lo = bf_lo(wv[e]), hi = bf_hi(wv[e]);
+        if (xf) { lo = fmaf(lo, sc[2 * e], sh[2 * e]); hi = fmaf(hi, sc[2 * e + 1], sh[2 * e + 1]); }
+        lo = act_f(lo, act); hi = act_f(hi, act);
+        wv[e] = pack_bf16x2(lo, hi);
+    }
+    return make_uint4(wv[0], wv[1], wv[2], wv[3]);
+}
+
+}  // namespace unet
