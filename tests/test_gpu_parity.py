@@ -109,7 +109,7 @@ def test_convt_ops(case, dt):
     x = q(rnd((cin, D, H, W), 1), dt); w = rnd((cin, cout, 2, 2, 2), 2, 0.3); b = rnd((cout,), 3)
     y_ref = np.empty((cout, 2 * D, 2 * H, 2 * W), np.float32)
     l.orc_convt_fwd(O._f(x), O._f(w), O._f(b), O._f(y_ref), cin, cout, D, H, W)
-    sc = scratch(cin, cout)
+    sc = scratch(cin, cout, D, H, W)
     wd, bd, xd = torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV), to_cl(x, dt)
     yd = torch.empty((2 * D, 2 * H, 2 * W, cout), dtype=TDT[dt], device=DEV)
     E.check(E.lib.unet_op_convt_fwd(EDT[dt], 0, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), cin, cout, D, H, W,

@@ -151,8 +151,20 @@ struct unet_plan {
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
-            size_t b = wgrad_direct_scratch_bytes(op_geom_of(op), op.kind == OP_CONVT);
+            ConvGeom cg = op_geom_of(op);
+            size_t b = wgrad_direct_scratch_bytes(cg, op.kind == OP_CONVT);
             if (b > wmax) wmax = b;
+            if (op.kind == OP_CONVT && impl == UNET_IMPL_AUTO) {
+                SrcDesc sd[2];
+                for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
+                if (mfma_convt_wgrad_supported(dtype, cg, sd, op.nsrc)) {
+                    wgrad_mfma[i] = 1;
+                    b = mfma_convt_wgrad_scratch_bytes(cg);
+                    if (b > wmax) wmax = b;
+                    b = bias_grad_scratch_bytes(cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo);
+                    if (b > wmax) wmax = b;
+                }
+            }
         }
         wgrad_off = take(wmax ? wmax : 256);
         ws_bytes = off;
@@ -331,7 +343,12 @@ struct Exec {
                         if (any && p.dgrad_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
-                        launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                        if (p.wgrad_mfma[i]) {
+                            launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + p.wgrad_off, s);
+                            launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, s);
+                        } else {
+                            launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                        }
                         if (any && p.dgrad_mfma[i]) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     }
@@ -599,6 +616,9 @@ int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes)
         g.stride = 2; g.Do = (D - 1) / 2 + 1; g.Ho = (H - 1) / 2 + 1; g.Wo = (W - 1) / 2 + 1;
         w = mfma_wgrad_scratch_bytes(g);
         if (w > b) b = w;
+        g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W;   // conv_trans
+        w = mfma_convt_wgrad_scratch_bytes(g);
+        if (w > b) b = w;
     }
     *bytes = b;
     return 0;
@@ -706,10 +726,14 @@ int unet_op_convt_bwd_data(int dtype, int impl, const void* dy, const float* w, 
 int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout, int D, int H,
                              int W, void* scratch, void* stream) {
     OP_TRY({
-        (void)impl; (void)scratch;
         ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
         SrcDesc sd; sd.ptr = x; sd.C = cin;
-        launch_convt_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);
+        if (impl == UNET_IMPL_AUTO && mfma_convt_wgrad_supported(dtype, g, &sd, 1)) {
+            launch_mfma_convt_wgrad(g, &sd, dy, dw, scratch, (hipStream_t)stream);
+            if (db) launch_bias_grad(dtype, dy, cout, (int64_t)g.Do * g.Ho * g.Wo, db, nullptr, (hipStream_t)stream);
+        } else {
+            launch_convt_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);
+        }
     })
 }
 int unet_op_pack_ndhwc(int dtype, const float* x, void* y, int C, int64_t S, void* stream) {

@@ -127,6 +127,12 @@ bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int 
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s);
+// conv_trans wgrad (single source); bias grad separately (launch_bias_grad)
+bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g);
+void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s);
+size_t bias_grad_scratch_bytes(int C, int64_t S);
+void launch_bias_grad(int dtype, const void* dy, int C, int64_t S, float* db, void* scratch, hipStream_t s);
 // dgrad of a 3x3x3 conv, stride 1 or 2 (g = forward geometry)
 bool mfma_conv_dgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_conv_dgrad_w_bytes(const ConvGeom& g);

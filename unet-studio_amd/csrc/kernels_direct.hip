@@ -350,6 +350,15 @@ static void launch_wgrad_common(int dtype, const ConvGeom& g, const SrcDesc* src
         if (bs > 1) k_slab_reduce<<<cdiv64(g.Cout, 256), 256, 0, s>>>(bslab, bs, g.Cout, db);
     }
 }
+// db[c] += sum_v dy[v][c]   (scratch: bias_grad_scratch_bytes, or nullptr for a single-block-per-channel pass)
+size_t bias_grad_scratch_bytes(int C, int64_t S) { return (size_t)bias_split(S) * C * 4 + 256; }
+void launch_bias_grad(int dtype, const void* dy, int C, int64_t S, float* db, void* scratch, hipStream_t s) {
+    int bs = scratch ? bias_split(S) : 1;
+    float* bslab = bs > 1 ? (float*)scratch : nullptr;
+    UNET_DISPATCH(dtype, (k_bias_grad<T><<<dim3(C, bs), 256, 0, s>>>((const T*)dy, C, S, db, bslab)));
+    if (bs > 1) k_slab_reduce<<<cdiv64(C, 256), 256, 0, s>>>(bslab, bs, C, db);
+}
+
 void launch_conv_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
                               void* scratch, hipStream_t s) {
     launch_wgrad_common(dtype, g, src, nsrc, dy, dw, db, 0, scratch, s);

@@ -1,33 +1,33 @@
-// MFMA wgrad kernels for gfx950 (bf16 storage, fp32 accumulate).  See the block comment below.
+// MFMA weight-gradient kernels for gfx950 (bf16 storage, fp32 accumulate).
+//
+//   conv 3x3x3 (stride 1 or 2):   dW[co][ci][t] = sum_v  a[v*S + t - 1][ci] * dy[v][co]      (a = transformed conv input)
+//   conv_trans 2x2x2 stride 2:    dW[ci][co][t] = sum_v  x[v][ci] * dy[2v + t][co]           (x = transformed input)
+// Both are T implicit GEMMs  D_t[ca][cb] += A_t[ca][k] * B[k][cb]  with k = voxel of the tile-side ("B") tensor and the
+// halo-side ("A") tensor read at k*S + t - PAD:  conv: A = input, B = dy;  conv_trans: A = dy (fine grid), B = input.
+//   * K runs over voxels, but both tensors are channels-last, so both MFMA operands are read with the
+//     hardware-transposing ds_read_b64_tr_b16 (4 voxels x 16 channels per 16-lane group) from LDS planes
+//     [16-channel tile][voxel][16 ch] (32-B voxels: a 32-lane half covers one whole 256-B bank row).
+//   * one K-step = 32 tile voxels = 8 groups of 4 consecutive x; lane group gq and read r fetch group gq + 4r of
+//     the step, identically for A and B.
+//   * a block = PI x PJ (ca-tile, cb-tile) pairs, one pair per wave (4/(PI*PJ) waves per pair split the K-steps);
+//     every wave keeps all T tap accumulators in registers (27 taps: 108 VGPRs) across the block's tiles.
+//   * no float atomics: each block writes its partial to a slab [split][T][Ca][Cb]; a second kernel sums the slabs
+//     in a fixed order and adds into the fp32 gradient in torch layout (+=, as .grad accumulates).
+//   * conv: dL/dbias = sum_v dy[v][co] is accumulated by the threads that stage dy (blocks of ca-tile 0 only).
 #include "mfma_util.h"
 
 namespace unet {
 
-// ================================================================================================
-// wgrad of Conv3d 3x3x3 (stride 1 or 2):  dW[tap][ci][co] = sum over output voxels v of
-//     a[v*stride + tap - 1][ci] * dy[v][co]          (a = the conv's transformed input, zero padded)
-// as 27 implicit GEMMs  D_tap[ci][co] += A_tap[ci][k] * B[k][co]  with k = output voxel.
-//   * K runs over voxels, but both tensors are channels-last, so both MFMA operands are read with the
-//     hardware-transposing ds_read_b64_tr_b16 (4 voxels x 16 channels per 16-lane group) from LDS planes
-//     [16-channel tile][voxel][16 ch] (32-B voxels: a 32-lane half covers one whole 256-B bank row).
-//   * one K-step = 32 output voxels = 8 groups of 4 consecutive x; lane group gq and read r fetch group
-//     gq + 4r of the step, identically for A and B.
-//   * a block = PI x PJ (ci-tile, co-tile) pairs, one pair per wave (4/(PI*PJ) waves per pair split the
-//     K-steps); every wave keeps all 27 tap accumulators (108 VGPRs) in registers across the block's tiles.
-//   * no float atomics: each block writes its partial to a slab [split][27][Cin][Cout]; a second kernel sums
-//     the slabs in a fixed order and adds into the fp32 gradient in torch layout (+=, as .grad accumulates).
-//   * dL/dbias = sum_v dy[v][co] is accumulated by the threads that stage dy (blocks of ci-tile 0 only).
-// ================================================================================================
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct MfmaWgradArgs {
-    ConvGeom g;
-    SrcDesc src[2];
-    int nsrc;
-    const void* dy;
-    float* slab;       // [nsplit][27][Cin][Cout]
-    float* bias_slab;  // [nsplit][Cout] or nullptr
+    ConvGeom g;        // Cin = Ca (halo-side channels), Cout = Cb (tile-side channels); D,H,W = A volume; Do,Ho,Wo = B volume
+    SrcDesc asrc[2];   // halo side (may be a channel concat)
+    int nasrc;
+    SrcDesc bsrc;      // tile side
+    float* slab;       // [nsplit][T][Ca][Cb]
+    float* bias_slab;  // [nsplit][Cb] or nullptr: per-channel sums of the RAW tile-side tensor
     int tiles_x, tiles_y, tiles_z;
 };
 
@@ -37,10 +37,10 @@ __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int S, int BZ, int BY, int BX, int PI, int PJ>
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int PI, int PJ>
 __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
-    constexpr int HZ = (BZ - 1) * S + 3, HY = (BY - 1) * S + 3, HX = (BX - 1) * S + 3;
-    constexpr int NVA = HZ * HY * HX, NVB = BZ * BY * BX;
+    constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD;
+    constexpr int NVA = HZ * HY * HX, NVB = BZ * BY * BX, T = KD * KD * KD;
     constexpr int PLANE_A = NVA * 32, PLANE_B = NVB * 32, B_OFF = PI * PLANE_A;
     constexpr int P = PI * PJ, WPP = 4 / P;       // pairs per block, waves per pair
     constexpr int GPR = BX / 4;                   // 4-voxel groups per row
@@ -57,11 +57,11 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
     const int COTB = (g.Cout / 16) / PJ;
     const int ciB = (blockIdx.y / COTB) * PI, coB = (blockIdx.y % COTB) * PJ;
     const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    const int C0 = a.src[0].C;
+    const int C0 = a.asrc[0].C;
 
-    f32x4 acc[27];
+    f32x4 acc[T];
 #pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
@@ -69,10 +69,9 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
     // staging roles (fixed per thread): A units (plane, half) and B units (plane, half)
     constexpr int GA = PI * 2, GB = PJ * 2;
     const int ua = tid % GA, ub = tid % GB;
-    // source of this thread's A channels
     const int ca = (ciB + (ua >> 1)) * 16 + (ua & 1) * 8;
-    const int sa = (a.nsrc > 1 && ca >= C0) ? 1 : 0;
-    const SrcDesc& sd = a.src[sa];
+    const int sa = (a.nasrc > 1 && ca >= C0) ? 1 : 0;
+    const SrcDesc& sd = a.asrc[sa];
     const int cla = ca - (sa ? C0 : 0);
     float sc[8], sh[8];
     const bool xf = sd.scale != nullptr;
@@ -83,14 +82,21 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
     const int act = sd.act;
     const char* abase = (const char*)sd.ptr + (size_t)cla * 2;
     const int cb = (coB + (ub >> 1)) * 16 + (ub & 1) * 8;
-    const char* bbase = (const char*)a.dy + (size_t)cb * 2;
+    const char* bbase = (const char*)a.bsrc.ptr + (size_t)cb * 2;
+    float scb[8], shb[8];
+    const bool xfb = a.bsrc.scale != nullptr;
+    if (xfb) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { scb[e] = a.bsrc.scale[cb + e]; shb[e] = a.bsrc.shift[cb + e]; }
+    }
+    const int actb = a.bsrc.act;
     const bool do_bias = a.bias_slab != nullptr && ciB == 0;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ox0 = (tile % a.tiles_x) * BX, oy0 = ((tile / a.tiles_x) % a.tiles_y) * BY, oz0 = (tile / (a.tiles_x * a.tiles_y)) * BZ;
-        const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1, iz0 = oz0 * S - 1;
+        const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD, iz0 = oz0 * S - PAD;
         __syncthreads();
-        // ---- stage A: transformed input halo tile ----
+        // ---- stage A: halo tile ----
         {
             constexpr int UNITS = NVA * GA, ITERS = (UNITS + 255) / 256;
 #pragma unroll 4
@@ -103,24 +109,13 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
                     if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
                         size_t vox = ((size_t)gz * g.H + gy) * g.W + gx;
-                        v = *(const uint4*)(abase + vox * (size_t)sd.C * 2);
-                        if (xf || act) {
-                            unsigned wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float lo = bf_lo(wv[e]), hi = bf_hi(wv[e]);
-                                if (xf) { lo = fmaf(lo, sc[2 * e], sh[2 * e]); hi = fmaf(hi, sc[2 * e + 1], sh[2 * e + 1]); }
-                                lo = act_f(lo, act); hi = act_f(hi, act);
-                                wv[e] = pack_bf16x2(lo, hi);
-                            }
-                            v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-                        }
+                        v = transform8(*(const uint4*)(abase + vox * (size_t)sd.C * 2), xf, sc, sh, act);
                     }
                     *(uint4*)(smem + (ua >> 1) * PLANE_A + hv * 32 + (ua & 1) * 16) = v;
                 }
             }
         }
-        // ---- stage B: dy tile (+ bias partial sums) ----
+        // ---- stage B: tile (+ bias partial sums of the raw values) ----
         {
             constexpr int UNITS = NVB * GB, ITERS = (UNITS + 255) / 256;
 #pragma unroll 4
@@ -138,6 +133,7 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
                             bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
                             bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
                         }
+                        v = transform8(v, xfb, scb, shb, actb);
                     }
                     *(uint4*)(smem + B_OFF + (ub >> 1) * PLANE_B + tv * 32 + (ub & 1) * 16) = v;
                 }
@@ -160,8 +156,8 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
             }
             bf16x8 bfrag = tr_read2(pb + bo[0], pb + bo[1]);
 #pragma unroll
-            for (int t = 0; t < 27; ++t) {
-                const int toff = (((t / 9) * HY + (t / 3) % 3) * HX + t % 3) * 32;
+            for (int t = 0; t < T; ++t) {
+                const int toff = (((t / (KD * KD)) * HY + (t / KD) % KD) * HX + t % KD) * 32;
                 bf16x8 afrag = tr_read2(pa + ao[0] + toff, pa + ao[1] + toff);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc[t], 0, 0, 0);
             }
@@ -170,18 +166,18 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
 
     // ---- reduce the K-split waves of each pair through LDS, then write the slab ----
     __syncthreads();
-    float* red = (float*)smem;   // [P][27][64][4]
+    float* red = (float*)smem;   // [P][T][64][4]
 #pragma unroll 1
     for (int kk = 1; kk < WPP; ++kk) {
         if (kw == kk) {
 #pragma unroll
-            for (int t = 0; t < 27; ++t) *(f32x4*)(red + ((pw * 27 + t) * 64 + lane) * 4) = acc[t];
+            for (int t = 0; t < T; ++t) *(f32x4*)(red + ((pw * T + t) * 64 + lane) * 4) = acc[t];
         }
         __syncthreads();
         if (kw == 0) {
 #pragma unroll
-            for (int t = 0; t < 27; ++t) {
-                f32x4 o = *(const f32x4*)(red + ((pw * 27 + t) * 64 + lane) * 4);
+            for (int t = 0; t < T; ++t) {
+                f32x4 o = *(const f32x4*)(red + ((pw * T + t) * 64 + lane) * 4);
                 acc[t][0] += o[0]; acc[t][1] += o[1]; acc[t][2] += o[2]; acc[t][3] += o[3];
             }
         }
@@ -189,9 +185,9 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
     }
     if (kw == 0) {
         const int ci = (ciB + it_) * 16 + gq * 4, co = (coB + jt) * 16 + il;
-        float* sl = a.slab + (size_t)blockIdx.x * 27 * g.Cin * g.Cout;
+        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout;
 #pragma unroll
-        for (int t = 0; t < 27; ++t)
+        for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sl[((size_t)t * g.Cin + ci + r) * g.Cout + co] = acc[t][r];
     }
@@ -212,111 +208,151 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
     }
 }
 
-// dw[co][ci][tap] += sum_split slab[split][tap][ci][co];  db[co] += sum_split bias_slab[split][co]
-__global__ void k_mfma_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ bias_slab, int nsplit, int Cin, int Cout,
-                                    float* __restrict__ dw, float* __restrict__ db) {
-    int64_t n = (int64_t)27 * Cin * Cout;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// dw[(cb*Ca + ca)*T + t] += sum_split slab[split][t][ca][cb];  db[cb] += sum_split bias_slab[split][cb].
+// 32 consecutive outputs x 8 split lanes per block: coalesced slab reads, fixed summation order.
+__global__ void __launch_bounds__(256) k_mfma_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ bias_slab, int nsplit,
+                                                           int T, int Ca, int Cb, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double red[8][32];
+    const int64_t n = (int64_t)T * Ca * Cb, ntot = n + (db && bias_slab ? Cb : 0);
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + lx;
+    double s = 0.0;
     if (i < n) {
-        double s = 0.0;
-        for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * n + i];
-        int co = (int)(i % Cout); int64_t r = i / Cout;
-        int ci = (int)(r % Cin); int t = (int)(r / Cin);
-        dw[((int64_t)co * Cin + ci) * 27 + t] += (float)s;
-    } else if (db && bias_slab && i - n < Cout) {
-        int c = (int)(i - n);
-        double s = 0.0;
-        for (int k = 0; k < nsplit; ++k) s += bias_slab[(int64_t)k * Cout + c];
-        db[c] += (float)s;
+        for (int k = ly; k < nsplit; k += 8) s += slab[(int64_t)k * n + i];
+    } else if (i < ntot) {
+        for (int k = ly; k < nsplit; k += 8) s += bias_slab[(int64_t)k * Cb + (i - n)];
+    }
+    red[ly][lx] = s;
+    __syncthreads();
+    if (ly == 0 && i < ntot) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += red[k][lx];
+        if (i < n) {
+            int cb = (int)(i % Cb); int64_t r = i / Cb;
+            int ca = (int)(r % Ca); int t = (int)(r / Ca);
+            dw[((int64_t)cb * Ca + ca) * T + t] += (float)tot;
+        } else {
+            db[i - n] += (float)tot;
+        }
     }
 }
 
-bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
-    if (dtype != 1 || g.ks != 3 || (g.stride != 1 && g.stride != 2)) return false;
+static bool chan16(const ConvGeom& g, const SrcDesc* src, int nsrc) {
     if (g.Cin % 16 || g.Cout % 16) return false;
     for (int s = 0; s < nsrc; ++s)
         if (src[s].C % 16) return false;
     return true;
 }
+bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    return dtype == 1 && g.ks == 3 && (g.stride == 1 || g.stride == 2) && chan16(g, src, nsrc);
+}
+bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    return dtype == 1 && nsrc == 1 && chan16(g, src, nsrc);
+}
 
+// kind 0: conv stride 1, 1: conv stride 2, 2: conv_trans.  Ca/Cb and the tile-side grid width decide the configuration.
 struct WgradCfg { int bz, by, bx, pi, pj, nsplit, gy; };
-static WgradCfg wgrad_cfg(const ConvGeom& g) {
+static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
     WgradCfg c;
-    int cit = g.Cin / 16, cot = g.Cout / 16;
-    if (g.stride == 1) {
-        c.pi = cit % 2 == 0 ? 2 : 1; c.pj = cot % 2 == 0 ? 2 : 1;
-        if (g.Wo >= 12) { c.bz = 2; c.by = 8; c.bx = 16; }
-        else if (g.Wo > 4) { c.bz = 4; c.by = 8; c.bx = 8; }
+    int cat = Ca / 16, cbt = Cb / 16;
+    if (kind == 0) {
+        c.pi = cat % 2 == 0 ? 2 : 1; c.pj = cbt % 2 == 0 ? 2 : 1;
+        if (bW >= 12) { c.bz = 2; c.by = 8; c.bx = 16; }
+        else if (bW > 4) { c.bz = 4; c.by = 8; c.bx = 8; }
         else { c.bz = 4; c.by = 8; c.bx = 4; }
     } else {
-        c.pi = 1; c.pj = cot % 4 == 0 ? 4 : (cot % 2 == 0 ? 2 : 1);
-        if (g.Wo >= 12) { c.bz = 2; c.by = 4; c.bx = 16; }
-        else if (g.Wo > 4) { c.bz = 2; c.by = 8; c.bx = 8; }
+        c.pi = 1; c.pj = cbt % 4 == 0 ? 4 : (cbt % 2 == 0 ? 2 : 1);
+        if (bW >= 12) { c.bz = 2; c.by = 4; c.bx = 16; }
+        else if (bW > 4) { c.bz = 2; c.by = 8; c.bx = 8; }
         else { c.bz = 4; c.by = 8; c.bx = 4; }
     }
-    c.gy = (cit / c.pi) * (cot / c.pj);
-    int tiles = ((g.Wo + c.bx - 1) / c.bx) * ((g.Ho + c.by - 1) / c.by) * ((g.Do + c.bz - 1) / c.bz);
-    int want = 1024 / c.gy;
+    c.gy = (cat / c.pi) * (cbt / c.pj);
+    int tiles = ((bW + c.bx - 1) / c.bx) * ((bH + c.by - 1) / c.by) * ((bD + c.bz - 1) / c.bz);
+    int want = 512 / c.gy;
     if (want < 1) want = 1;
     c.nsplit = tiles < want ? tiles : want;
     return c;
 }
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g) {
-    WgradCfg c = wgrad_cfg(g);
+    WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
     return ((size_t)c.nsplit * 27 * g.Cin * g.Cout + (size_t)c.nsplit * g.Cout) * 4 + 256;
 }
+size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g) {
+    WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
+    return (size_t)c.nsplit * 8 * g.Cin * g.Cout * 4 + 256;
+}
 
-template <int S, int BZ, int BY, int BX, int PI, int PJ>
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int PI, int PJ>
 static void launch_wgrad_cfg(const MfmaWgradArgs& a0, const WgradCfg& c, hipStream_t s) {
     MfmaWgradArgs a = a0;
     a.tiles_x = (a.g.Wo + BX - 1) / BX; a.tiles_y = (a.g.Ho + BY - 1) / BY; a.tiles_z = (a.g.Do + BZ - 1) / BZ;
-    constexpr int HZ = (BZ - 1) * S + 3, HY = (BY - 1) * S + 3, HX = (BX - 1) * S + 3;
+    constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD, T = KD * KD * KD;
     constexpr size_t tile_lds = (size_t)PI * HZ * HY * HX * 32 + (size_t)PJ * BZ * BY * BX * 32;
-    constexpr size_t red_lds = PI * PJ < 4 ? (size_t)(PI * PJ) * 27 * 64 * 16 : 0;   // only K-split waves reduce through LDS
+    constexpr size_t red_lds = PI * PJ < 4 ? (size_t)(PI * PJ) * T * 64 * 16 : 0;   // only K-split waves reduce through LDS
     constexpr size_t lds = tile_lds > red_lds ? (tile_lds > 8192 ? tile_lds : 8192) : red_lds;
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_wgrad<S, BZ, BY, BX, PI, PJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid((unsigned)c.nsplit, (unsigned)c.gy);
-    k_mfma_wgrad<S, BZ, BY, BX, PI, PJ><<<grid, 256, lds, s>>>(a);
+    k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ><<<grid, 256, lds, s>>>(a);
 }
-template <int S, int BZ, int BY, int BX>
+template <int S, int KD, int PAD, int BZ, int BY, int BX>
 static void launch_wgrad_p(const MfmaWgradArgs& a, const WgradCfg& c, hipStream_t s) {
     if (S == 1) {
-        if (c.pi == 2 && c.pj == 2) launch_wgrad_cfg<S, BZ, BY, BX, 2, 2>(a, c, s);
-        else if (c.pi == 2) launch_wgrad_cfg<S, BZ, BY, BX, 2, 1>(a, c, s);
-        else if (c.pj == 2) launch_wgrad_cfg<S, BZ, BY, BX, 1, 2>(a, c, s);
-        else launch_wgrad_cfg<S, BZ, BY, BX, 1, 1>(a, c, s);
+        if (c.pi == 2 && c.pj == 2) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 2, 2>(a, c, s);
+        else if (c.pi == 2) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 2, 1>(a, c, s);
+        else if (c.pj == 2) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 1, 2>(a, c, s);
+        else launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 1, 1>(a, c, s);
     } else {
-        if (c.pj == 4) launch_wgrad_cfg<S, BZ, BY, BX, 1, 4>(a, c, s);
-        else if (c.pj == 2) launch_wgrad_cfg<S, BZ, BY, BX, 1, 2>(a, c, s);
-        else launch_wgrad_cfg<S, BZ, BY, BX, 1, 1>(a, c, s);
+        if (c.pj == 4) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 1, 4>(a, c, s);
+        else if (c.pj == 2) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 1, 2>(a, c, s);
+        else launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 1, 1>(a, c, s);
     }
 }
 
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s) {
-    WgradCfg c = wgrad_cfg(g);
+    WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
     MfmaWgradArgs a;
-    a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
-    a.dy = dy;
+    a.g = g; a.nasrc = nsrc; a.asrc[0] = src[0]; if (nsrc > 1) a.asrc[1] = src[1];
+    a.bsrc = SrcDesc(); a.bsrc.ptr = dy; a.bsrc.C = g.Cout;
     a.slab = (float*)scratch;
     a.bias_slab = db ? a.slab + (size_t)c.nsplit * 27 * g.Cin * g.Cout : nullptr;
     a.tiles_x = a.tiles_y = a.tiles_z = 0;
     if (g.stride == 1) {
-        if (g.Wo >= 12) launch_wgrad_p<1, 2, 8, 16>(a, c, s);
-        else if (g.Wo > 4) launch_wgrad_p<1, 4, 8, 8>(a, c, s);
-        else launch_wgrad_p<1, 4, 8, 4>(a, c, s);
+        if (g.Wo >= 12) launch_wgrad_p<1, 3, 1, 2, 8, 16>(a, c, s);
+        else if (g.Wo > 4) launch_wgrad_p<1, 3, 1, 4, 8, 8>(a, c, s);
+        else launch_wgrad_p<1, 3, 1, 4, 8, 4>(a, c, s);
     } else {
-        if (g.Wo >= 12) launch_wgrad_p<2, 2, 4, 16>(a, c, s);
-        else if (g.Wo > 4) launch_wgrad_p<2, 2, 8, 8>(a, c, s);
-        else launch_wgrad_p<2, 4, 8, 4>(a, c, s);
+        if (g.Wo >= 12) launch_wgrad_p<2, 3, 1, 2, 4, 16>(a, c, s);
+        else if (g.Wo > 4) launch_wgrad_p<2, 3, 1, 2, 8, 8>(a, c, s);
+        else launch_wgrad_p<2, 3, 1, 4, 8, 4>(a, c, s);
     }
-    int64_t n = (int64_t)27 * g.Cin * g.Cout + g.Cout;
-    k_mfma_wgrad_reduce<<<cdiv64(n, 256), 256, 0, s>>>(a.slab, a.bias_slab, c.nsplit, g.Cin, g.Cout, dw, db);
+    int64_t n = (int64_t)27 * g.Cin * g.Cout + (db ? g.Cout : 0);
+    k_mfma_wgrad_reduce<<<cdiv64(n, 32), 256, 0, s>>>(a.slab, a.bias_slab, c.nsplit, 27, g.Cin, g.Cout, dw, db);
+}
+
+// conv_trans wgrad (g = forward geometry of the conv_trans: D,H,W coarse input, Do,Ho,Wo fine output).
+// halo side A = dy (fine, Cout channels), tile side B = transformed input (coarse, Cin channels): D_t[co][ci].
+void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s) {
+    WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
+    MfmaWgradArgs a;
+    a.g.Cin = g.Cout; a.g.Cout = g.Cin; a.g.D = g.Do; a.g.H = g.Ho; a.g.W = g.Wo; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
+    a.g.ks = 2; a.g.stride = 2;
+    a.nasrc = 1; a.asrc[0] = SrcDesc(); a.asrc[0].ptr = dy; a.asrc[0].C = g.Cout;
+    a.bsrc = src[0];
+    a.slab = (float*)scratch; a.bias_slab = nullptr;
+    a.tiles_x = a.tiles_y = a.tiles_z = 0;
+    if (g.W >= 12) launch_wgrad_p<2, 2, 0, 2, 4, 16>(a, c, s);
+    else if (g.W > 4) launch_wgrad_p<2, 2, 0, 2, 8, 8>(a, c, s);
+    else launch_wgrad_p<2, 2, 0, 4, 8, 4>(a, c, s);
+    // slab[t][ca = co][cb = ci] -> dw[(ci*Cout + co)*8 + t]
+    int64_t n = (int64_t)8 * g.Cin * g.Cout;
+    k_mfma_wgrad_reduce<<<cdiv64(n, 32), 256, 0, s>>>(a.slab, nullptr, c.nsplit, 8, g.Cout, g.Cin, dw, nullptr);
 }
 
 }  // namespace unet
