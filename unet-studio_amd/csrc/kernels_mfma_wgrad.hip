@@ -302,7 +302,7 @@ static void launch_wgrad_cfg(const MfmaWgradArgs& a0, const WgradCfg& c, hipStre
 }
 template <int S, int KD, int PAD, int BZ, int BY, int BX>
 static void launch_wgrad_p(const MfmaWgradArgs& a, const WgradCfg& c, hipStream_t s) {
-    if (S == 1) {
+    if constexpr (S == 1) {
         if (c.pi == 2 && c.pj == 2) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 2, 2>(a, c, s);
         else if (c.pi == 2) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 2, 1>(a, c, s);
         else if (c.pj == 2) launch_wgrad_cfg<S, KD, PAD, BZ, BY, BX, 1, 2>(a, c, s);
