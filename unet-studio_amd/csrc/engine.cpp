@@ -154,6 +154,10 @@ struct unet_plan {
             ConvGeom cg = op_geom_of(op);
             size_t b = wgrad_direct_scratch_bytes(cg, op.kind == OP_CONVT);
             if (b > wmax) wmax = b;
+            if (op.kind == OP_CONV && wgrad_small_supported(cg)) {
+                b = wgrad_small_scratch_bytes(cg);
+                if (b > wmax) wmax = b;
+            }
             if (op.kind == OP_CONVT && impl == UNET_IMPL_AUTO) {
                 SrcDesc sd[2];
                 for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
@@ -338,6 +342,8 @@ struct Exec {
                     if (op.kind == OP_CONV) {
                         if (p.wgrad_mfma[i])
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                        else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg))
+                            launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
                         else
                             launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
                         if (any && p.dgrad_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
@@ -608,6 +614,10 @@ int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, f
 int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes) {
     size_t b = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096 +
                align_up((size_t)160 * round_up(cin, 32) * round_up(cout, 32));   // largest MFMA filter pack: stride-2 dgrad, 128 B per Cin*Cout
+    if ((int64_t)cin * cout <= 1024) {   // small-weight wgrad slabs: <= 1024 row blocks x <= 1024 weights, + bias partials
+        size_t w = ((size_t)1024 * 1024 + (size_t)256 * cout) * 4 + 256;
+        if (w > b) b = w;
+    }
     if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {
         ConvGeom g;   // MFMA wgrad slabs: stride-1 geometry has the most tiles
         g.Cin = cin; g.Cout = cout; g.D = g.Do = D; g.H = g.Ho = H; g.W = g.Wo = W; g.ks = 3; g.stride = 1;
@@ -684,6 +694,8 @@ int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy
         SrcDesc sd; sd.ptr = x; sd.C = cin;
         if (impl == UNET_IMPL_AUTO && mfma_wgrad_supported(dtype, g, &sd, 1))
             launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
+        else if (impl == UNET_IMPL_AUTO && wgrad_small_supported(g))
+            launch_conv_wgrad_small(dtype, g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
         else
             launch_conv_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);
     })

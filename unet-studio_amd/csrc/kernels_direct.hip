@@ -442,4 +442,98 @@ void launch_convt_dgrad_direct(int dtype, const ConvGeom& g, const void* dy, con
     UNET_DISPATCH(dtype, (k_convt_dgrad_direct<T><<<grid, 256, 0, s>>>(a)));
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad for layers with few weights (k3*Cin*Cout <= 1024: the Cin = 1 first conv, the 6-channel 1x1 heads):
+// every block owns a strided set of output rows, stages the row's input neighbourhood and dy in LDS (fp32, input
+// already transformed) and every thread accumulates up to 4 weight gradients over the row.  Per-block partials go
+// to a slab that k_slab_reduce sums in a fixed order.  HBM-bound: reads dy and the input once.
+// ------------------------------------------------------------------------------------------------
+struct WgradSmallArgs {
+    ConvGeom g;
+    SrcDesc src[2];
+    int nsrc;
+    const void* dy;
+    float* slab;   // [gridDim.x][k3*Cin*Cout]
+};
+
+template <typename T> __global__ void __launch_bounds__(256) k_wgrad_small(WgradSmallArgs a) {
+    extern __shared__ float sm[];
+    const ConvGeom& g = a.g;
+    const int ks = g.ks, k3 = ks * ks * ks, pad = (ks - 1) / 2;
+    const int O = k3 * g.Cin * g.Cout;
+    const int WI = (g.Wo - 1) * g.stride + ks;      // input columns a row of outputs touches
+    float* sa = sm;                                  // [ks*ks rows][WI][Cin]
+    float* sd = sm + ks * ks * WI * g.Cin;           // [Wo][Cout]
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int oc[4], oci[4], orow[4], okx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int o = threadIdx.x + k * 256;
+        if (o >= O) o = 0;
+        int tap = o % k3, r = o / k3;                // torch layout index = (co*Cin + ci)*k3 + tap
+        oci[k] = r % g.Cin; oc[k] = r / g.Cin;
+        orow[k] = tap / ks; okx[k] = tap % ks;       // orow = kz*ks + ky
+    }
+    const T* dy = (const T*)a.dy;
+    const int C0 = a.src[0].C;
+    for (int row = blockIdx.x; row < g.Do * g.Ho; row += gridDim.x) {
+        const int z = row / g.Ho, y = row % g.Ho;
+        __syncthreads();
+        for (int i = threadIdx.x; i < ks * ks * WI * g.Cin; i += 256) {
+            int ci = i % g.Cin, r = i / g.Cin;
+            int xi = r % WI, rr = r / WI;
+            int iz = z * g.stride + rr / ks - pad, iy = y * g.stride + rr % ks - pad, ix = xi - pad;
+            float v = 0.f;
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+                int64_t vox = ((int64_t)iz * g.H + iy) * g.W + ix;
+                v = (a.nsrc > 1 && ci >= C0) ? view_ld<T>(a.src[1], vox, ci - C0) : view_ld<T>(a.src[0], vox, ci);
+            }
+            sa[i] = v;
+        }
+        for (int i = threadIdx.x; i < g.Wo * g.Cout; i += 256) sd[i] = ld<T>(dy, (int64_t)row * g.Wo * g.Cout + i);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (threadIdx.x + k * 256 < O) {
+                const float* pa = sa + ((orow[k] * WI + okx[k]) * g.Cin + oci[k]);
+                const float* pd = sd + oc[k];
+                float r = 0.f;
+                for (int x = 0; x < g.Wo; ++x) r = fmaf(pa[x * g.stride * g.Cin], pd[x * g.Cout], r);
+                acc[k] += r;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int o = threadIdx.x + k * 256;
+        if (o < O) a.slab[(int64_t)blockIdx.x * O + o] = acc[k];
+    }
+}
+
+static int wgrad_small_blocks(const ConvGeom& g) { int rows = g.Do * g.Ho; return rows < 1024 ? rows : 1024; }
+bool wgrad_small_supported(const ConvGeom& g) {
+    int k3 = g.ks * g.ks * g.ks;
+    int WI = (g.Wo - 1) * g.stride + g.ks;
+    size_t lds = ((size_t)g.ks * g.ks * WI * g.Cin + (size_t)g.Wo * g.Cout) * 4;
+    return (int64_t)k3 * g.Cin * g.Cout <= 1024 && lds <= 48 * 1024;
+}
+size_t wgrad_small_scratch_bytes(const ConvGeom& g) {
+    int k3 = g.ks * g.ks * g.ks;
+    int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+    return ((size_t)wgrad_small_blocks(g) * k3 * g.Cin * g.Cout + (size_t)bias_split(So) * g.Cout) * 4 + 256;
+}
+void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
+                             void* scratch, hipStream_t s) {
+    WgradSmallArgs a;
+    a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
+    a.dy = dy; a.slab = (float*)scratch;
+    int nb = wgrad_small_blocks(g), k3 = g.ks * g.ks * g.ks;
+    int64_t O = (int64_t)k3 * g.Cin * g.Cout;
+    int WI = (g.Wo - 1) * g.stride + g.ks;
+    size_t lds = ((size_t)g.ks * g.ks * WI * g.Cin + (size_t)g.Wo * g.Cout) * 4;
+    UNET_DISPATCH(dtype, (k_wgrad_small<T><<<nb, 256, lds, s>>>(a)));
+    k_slab_reduce<<<cdiv64(O, 256), 256, 0, s>>>(a.slab, nb, O, dw);
+    if (db) launch_bias_grad(dtype, dy, g.Cout, (int64_t)g.Do * g.Ho * g.Wo, db, (float*)scratch + (size_t)nb * O, s);
+}
+
 }  // namespace unet

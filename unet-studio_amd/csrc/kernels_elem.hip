@@ -454,13 +454,20 @@ void launch_loss_partial(const float* logits, const int64_t* target, int C, int6
 __global__ void __launch_bounds__(256) k_loss_finalize(const float* __restrict__ partial, int nblk, int oc, float weight, int cost_mask,
                                                        float* level_out, float* totals, int set_stats) {
     extern __shared__ double shd[];  // 3 + 2*oc
+    __shared__ double redd[256];
     int np = 3 + 2 * oc;
-    for (int i = threadIdx.x; i < np; i += 256) {
+    for (int i = 0; i < np; ++i) {   // all 256 threads sum one value's partials, fixed-order tree
         double a = 0.0;
-        for (int b = 0; b < nblk; ++b) a += partial[(int64_t)b * np + i];
-        shd[i] = a;
+        for (int b = threadIdx.x; b < nblk; b += 256) a += partial[(int64_t)b * np + i];
+        redd[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) redd[threadIdx.x] += redd[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) shd[i] = redd[0];
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
         double n = shd[2] < 1.0 ? 1.0 : shd[2];
         double eps = (double)1e-5f, dsum = 0.0;

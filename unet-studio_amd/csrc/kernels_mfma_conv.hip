@@ -288,21 +288,31 @@ template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> stati
     if constexpr (SC) {   // scatter kinds always have ntt % 4 == 0 (rows = 8 * C, C % 16 == 0)
         launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, true>(a, s);
     } else {
-        if (ntt % 4 == 0) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
-        else if (ntt % 2 == 0) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
+        // row tiles per block: as many as divide the row count, fewer when the grid would not fill the 256 CUs
+        int tiles = ((a.g.Wo + BX - 1) / BX) * ((a.g.Ho + BY - 1) / BY) * ((a.g.Do + BZ - 1) / BZ);
+        int nt = ntt % 4 == 0 ? 4 : (ntt % 2 == 0 ? 2 : 1);
+        while (nt > 1 && (int64_t)tiles * (ntt / nt) < 256) nt >>= 1;
+        if (nt == 4) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
+        else if (nt == 2) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
         else launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, false>(a, s);
     }
 }
 
 // tile shapes per kind and output-grid width (every shape keeps the LDS tile <= 64 KB)
 struct Tile { int bz, by, bx; };
-static Tile tile_s1k3(int Wo, int CK) {
-    if (Wo >= 12) return CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16};
-    return Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4};
+static int tile_count(const ConvGeom& g, Tile t) { return ((g.Wo + t.bx - 1) / t.bx) * ((g.Ho + t.by - 1) / t.by) * ((g.Do + t.bz - 1) / t.bz); }
+// small volumes (the deep levels) get small tiles so that tiles x row-tiles still covers the chip
+static Tile tile_s1k3(const ConvGeom& g, int CK) {
+    Tile big = g.Wo >= 12 ? (CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16}) : (g.Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4});
+    if ((int64_t)tile_count(g, big) * (g.Cout / 16) >= 256) return big;
+    return g.Wo >= 12 ? Tile{2, 4, 16} : (g.Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4});
 }
 static void launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
-    if (a.g.Wo >= 12) { if (CK == 32) launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }
-    else if (a.g.Wo > 4) { if (CK == 32) launch_nt<1, 3, 1, 4, 8, 8, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 8, 16, false>(a, s); }
+    Tile t = tile_s1k3(a.g, CK);
+    if (t.bx == 16 && t.bz == 4) { if (CK == 32) launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }
+    else if (t.bx == 16) { if (CK == 32) launch_nt<1, 3, 1, 2, 4, 16, 32, false>(a, s); else launch_nt<1, 3, 1, 2, 4, 16, 16, false>(a, s); }
+    else if (t.bx == 8 && t.bz == 4) { if (CK == 32) launch_nt<1, 3, 1, 4, 8, 8, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 8, 16, false>(a, s); }
+    else if (t.bx == 8) { if (CK == 32) launch_nt<1, 3, 1, 2, 4, 8, 32, false>(a, s); else launch_nt<1, 3, 1, 2, 4, 8, 16, false>(a, s); }
     else { if (CK == 32) launch_nt<1, 3, 1, 4, 4, 4, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 4, 4, 16, false>(a, s); }
 }
 static Tile tile_s2k3(int Wo) { return Wo >= 12 ? Tile{2, 4, 16} : (Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4}); }
@@ -371,8 +381,8 @@ void launch_mfma_pack_conv_w(const float* w, void* w_fwd, void* w_dgrad, const C
     }
 }
 int mfma_conv_blocks(const ConvGeom& g) {
-    Tile t = g.stride == 1 ? tile_s1k3(g.Wo, fwd_ck(g)) : tile_s2k3(g.Wo);
-    return ((g.Wo + t.bx - 1) / t.bx) * ((g.Ho + t.by - 1) / t.by) * ((g.Do + t.bz - 1) / t.bz);
+    Tile t = g.stride == 1 ? tile_s1k3(g, fwd_ck(g)) : tile_s2k3(g.Wo);
+    return tile_count(g, t);
 }
 void launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
                           float* stats_partial, hipStream_t s) {
