@@ -274,12 +274,25 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(Wgra
 }
 
 // out[i] += sum_k slab[k][i]   (fixed order: deterministic)
-__global__ void k_slab_reduce(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// a block = 32 consecutive outputs x 8 split lanes: coalesced slab reads, 8 lanes share each output's split loop
+__global__ void __launch_bounds__(256) k_slab_reduce_k(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out) {
+    __shared__ double red[8][32];
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + lx;
     double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += slab[(int64_t)k * n + i];
-    out[i] += (float)s;
+    if (i < n)
+        for (int k = ly; k < nsplit; k += 8) s += slab[(int64_t)k * n + i];
+    red[ly][lx] = s;
+    __syncthreads();
+    if (ly == 0 && i < n) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += red[k][lx];
+        out[i] += (float)tot;
+    }
+}
+static void slab_reduce(const float* slab, int nsplit, int64_t n, float* out, hipStream_t s) {
+    k_slab_reduce_k<<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out);
 }
 
 // bias grad: db[c] += sum over voxels of dy[v][c]; one block per channel
@@ -341,13 +354,13 @@ static void launch_wgrad_common(int dtype, const ConvGeom& g, const SrcDesc* src
     a.slab = nsplit > 1 ? (float*)scratch : nullptr;
     dim3 grid((unsigned)(k3 * g.Cin), (unsigned)((g.Cout + CW - 1) / CW), (unsigned)nsplit);
     UNET_DISPATCH(dtype, (k_wgrad_direct<T><<<grid, 256, 0, s>>>(a)));
-    if (nsplit > 1) k_slab_reduce<<<cdiv64(a.total, 256), 256, 0, s>>>(a.slab, nsplit, a.total, dw);
+    if (nsplit > 1) slab_reduce(a.slab, nsplit, a.total, dw, s);
     if (db) {
         int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
         int bs = scratch ? bias_split(So) : 1;
         float* bslab = bs > 1 ? (float*)scratch + (size_t)nsplit * a.total : nullptr;
         UNET_DISPATCH(dtype, (k_bias_grad<T><<<dim3(g.Cout, bs), 256, 0, s>>>((const T*)dy, g.Cout, So, db, bslab)));
-        if (bs > 1) k_slab_reduce<<<cdiv64(g.Cout, 256), 256, 0, s>>>(bslab, bs, g.Cout, db);
+        if (bs > 1) slab_reduce(bslab, bs, g.Cout, db, s);
     }
 }
 // db[c] += sum_v dy[v][c]   (scratch: bias_grad_scratch_bytes, or nullptr for a single-block-per-channel pass)
@@ -356,7 +369,7 @@ void launch_bias_grad(int dtype, const void* dy, int C, int64_t S, float* db, vo
     int bs = scratch ? bias_split(S) : 1;
     float* bslab = bs > 1 ? (float*)scratch : nullptr;
     UNET_DISPATCH(dtype, (k_bias_grad<T><<<dim3(C, bs), 256, 0, s>>>((const T*)dy, C, S, db, bslab)));
-    if (bs > 1) k_slab_reduce<<<cdiv64(C, 256), 256, 0, s>>>(bslab, bs, C, db);
+    if (bs > 1) slab_reduce(bslab, bs, C, db, s);
 }
 
 void launch_conv_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
@@ -532,7 +545,7 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
     int WI = (g.Wo - 1) * g.stride + g.ks;
     size_t lds = ((size_t)g.ks * g.ks * WI * g.Cin + (size_t)g.Wo * g.Cout) * 4;
     UNET_DISPATCH(dtype, (k_wgrad_small<T><<<nb, 256, lds, s>>>(a)));
-    k_slab_reduce<<<cdiv64(O, 256), 256, 0, s>>>(a.slab, nb, O, dw);
+    slab_reduce(a.slab, nb, O, dw, s);
     if (db) launch_bias_grad(dtype, dy, g.Cout, (int64_t)g.Do * g.Ho * g.Wo, db, (float*)scratch + (size_t)nb * O, s);
 }
 
