@@ -110,6 +110,12 @@ int unet_sgd_step(const unet_plan* plan, float* params_flat, float* grads_flat, 
 int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes);
 int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D,
                        int H, int W, int ks, int stride, void* scratch, void* stream);
+/* conv3d with the read-side fusion of the engine: the input is seen as act(x*scale[c]+shift[c]) (scale/shift fp32 [cin] or
+ * NULL, act 0 none 1 relu 2 leaky_relu(0.01) 3 elu), zero padding applied after it; stats (may be NULL) receives the
+ * per-channel {sum, sum of squares} of the stored output, fp32 [cout][2] (what the following norm layer needs). */
+int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* scale, const float* shift, int act, const float* w,
+                             const float* b, void* y, float* stats, int cin, int cout, int D, int H, int W, int ks, int stride,
+                             void* scratch, void* stream);
 int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H,
                             int W, int ks, int stride, void* scratch, void* stream);
 int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout,

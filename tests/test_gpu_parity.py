@@ -100,6 +100,38 @@ def test_conv3d_ops(case, dt, impl):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("impl", [U.IMPL_DIRECT, U.IMPL_AUTO])
+@pytest.mark.parametrize("case", [(16, 16, (6, 9, 20), 3, 1, 2), (32, 32, (8, 8, 8), 3, 2, 3), (16, 32, (5, 6, 4), 3, 1, 1), (5, 7, (4, 5, 6), 3, 1, 2)])
+def test_conv3d_fused_prologue_epilogue(case, dt, impl):
+    """norm + activation applied by the consumer while it reads (zero padding AFTER the activation), and the
+    {sum, sum of squares} of the stored output that the next norm needs (unet.cpp:74-98 fused into unet.cpp:59-72)"""
+    cin, cout, (D, H, W), ks, st, act = case
+    l = O.lib()
+    x = q(rnd((cin, D, H, W), 1), dt); w = rnd((cout, cin, ks, ks, ks), 2, 0.2); b = rnd((cout,), 3)
+    scale = (1.0 + 0.3 * rnd((cin,), 5)).astype(np.float32); shift = rnd((cin,), 6, 0.5)
+    xn = x * scale[:, None, None, None] + shift[:, None, None, None]
+    xa = np.empty_like(xn)
+    l.orc_act_fwd(O._f(np.ascontiguousarray(xn)), O._f(xa), C.c_int64(xa.size), act)
+    xa = q(xa, dt)   # the engine rounds the transformed value to the element type before the MFMA
+    od = [(s + 2 - ks) // st + 1 for s in (D, H, W)]
+    y_ref = np.empty((cout, *od), np.float32)
+    l.orc_conv3d_fwd(O._f(xa), O._f(w), O._f(b), O._f(y_ref), cin, cout, D, H, W, ks, st)
+    sc = scratch(cin, cout, D, H, W)
+    wd, bd, xd = torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV), to_cl(x, dt)
+    sd, hd = torch.from_numpy(scale).to(DEV), torch.from_numpy(shift).to(DEV)
+    yd = torch.empty((*od, cout), dtype=TDT[dt], device=DEV)
+    stats = torch.empty((cout, 2), dtype=torch.float32, device=DEV)
+    E.check(E.lib.unet_op_conv3d_fwd_fused(EDT[dt], impl, xd.data_ptr(), sd.data_ptr(), hd.data_ptr(), act, wd.data_ptr(), bd.data_ptr(),
+                                           yd.data_ptr(), stats.data_ptr(), cin, cout, D, H, W, ks, st, sc.data_ptr(), stream()))
+    y = from_cl(yd)
+    assert rel(y, y_ref) < (1e-5 if dt == "fp32" else 1.5e-2)
+    got = stats.cpu().numpy().astype(np.float64)
+    yy = y.astype(np.float64).reshape(cout, -1)
+    assert np.allclose(got[:, 0], yy.sum(1), rtol=1e-4, atol=1e-3 * np.abs(yy).sum(1).max())
+    assert np.allclose(got[:, 1], (yy * yy).sum(1), rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", [(16, 16, (4, 5, 6)), (7, 3, (3, 4, 5)), (32, 16, (4, 4, 8)),
                                   # MFMA conv_trans (Cin % 32 == 0): every tile configuration, ragged edges
                                   (64, 32, (3, 5, 19)), (32, 32, (4, 4, 4)), (128, 64, (2, 3, 2)), (32, 48, (5, 9, 7))])

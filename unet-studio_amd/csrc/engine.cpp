@@ -614,6 +614,11 @@ int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, f
 int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes) {
     size_t b = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + 4096 +
                align_up((size_t)160 * round_up(cin, 32) * round_up(cout, 32));   // largest MFMA filter pack: stride-2 dgrad, 128 B per Cin*Cout
+    if (D > 0 && H > 0 && W > 0) {   // statistics partials of unet_op_conv3d_fwd_fused, behind the filter packs
+        int64_t S = (int64_t)D * H * W;
+        size_t blocks = (size_t)(S / 32 + 4096);   // >= any conv tile count (>= 64 voxels per tile, ragged edges) and >= stats_blocks(S)
+        b += align_up(blocks * cout * 2 * 4);
+    }
     if ((int64_t)cin * cout <= 1024) {   // small-weight wgrad slabs: <= 1024 row blocks x <= 1024 weights, + bias partials
         size_t w = ((size_t)1024 * 1024 + (size_t)256 * cout) * 4 + 256;
         if (w > b) b = w;
@@ -666,6 +671,33 @@ int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
             launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+        }
+    })
+}
+int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* scale, const float* shift, int act, const float* w,
+                             const float* b, void* y, float* stats, int cin, int cout, int D, int H, int W, int ks, int stride,
+                             void* scratch, void* stream) {
+    OP_TRY({
+        hipStream_t s = (hipStream_t)stream;
+        ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
+        float *wf, *wd;
+        SrcDesc sd; sd.ptr = x; sd.C = cin; sd.scale = scale; sd.shift = shift; sd.act = act;
+        int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+        // partials live behind the filter packs
+        size_t poff = 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4) + align_up((size_t)160 * round_up(cin, 32) * round_up(cout, 32));
+        float* part = (float*)((char*)scratch + poff);
+        if (impl == UNET_IMPL_AUTO && mfma_conv_fwd_supported(dtype, g, &sd, 1)) {
+            void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
+            launch_mfma_pack_conv_w(w, wm, nullptr, g, s);
+            launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, stats ? part : nullptr, s);
+            if (stats) launch_stats_sum(part, mfma_conv_blocks(g), cout, stats, s);
+        } else {
+            op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
+            launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+            if (stats) {
+                launch_stats_partial(dtype, y, cout, So, part, s);
+                launch_stats_sum(part, stats_blocks(So), cout, stats, s);
+            }
         }
     })
 }

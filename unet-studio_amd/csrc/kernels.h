@@ -69,6 +69,8 @@ void launch_stats_partial(int dtype, const void* x, int C, int64_t S, float* par
 // running stats (bnorm, may be nullptr): rm = (1-m)*rm + m*mean, rv = (1-m)*rv + m*unbiased var
 void launch_norm_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
                           float* stat, float* running_mean, float* running_var, double momentum, hipStream_t s);
+// partials -> out[c][2] = {sum, sum of squares}
+void launch_stats_sum(const float* partial, int nblk, int C, float* out, hipStream_t s);
 // eval-mode bnorm: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (mean := rm, rstd := 1/sqrt(rv+eps))
 void launch_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat,
                       hipStream_t s);

@@ -139,6 +139,16 @@ void launch_norm_finalize(const float* partial, int nblk, int C, int64_t S, cons
     k_norm_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, beta, eps, stat, rm, rv, momentum);
 }
 
+// out[c][j] = sum over blocks of partial[blk][c][j]   (one wave per channel, fp64, fixed order)
+__global__ void __launch_bounds__(64) k_stats_sum(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+    int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+    reduce2_wave(a, b);
+    if (threadIdx.x == 0) { out[c * 2] = (float)a; out[c * 2 + 1] = (float)b; }
+}
+void launch_stats_sum(const float* partial, int nblk, int C, float* out, hipStream_t s) { k_stats_sum<<<C, 64, 0, s>>>(partial, nblk, C, out); }
+
 __global__ void k_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat) {
     int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
