@@ -47,6 +47,7 @@ struct unet_plan {
     size_t elsize = 4;
     // workspace layout (byte offsets)
     std::vector<size_t> t_off, g_off;        // tensor storage / gradient storage (SIZE_MAX: none)
+    std::vector<size_t> a_off;               // activated copy act(norm(tensor)) that consumers read (SIZE_MAX: none)
     std::vector<size_t> n_stat, n_coef;      // per norm: 4C / 3C floats
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
     std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
@@ -81,9 +82,15 @@ struct unet_plan {
         auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
         t_off.assign(g.tensors.size(), SIZE_MAX);
         g_off.assign(g.tensors.size(), SIZE_MAX);
+        a_off.assign(g.tensors.size(), SIZE_MAX);
         for (size_t i = 0; i < g.tensors.size(); ++i) {
             t_off[i] = take((size_t)g.tensors[i].numel() * elsize);
             if (g.tensors[i].needs_grad) g_off[i] = take((size_t)g.tensors[i].numel() * elsize);
+            // Activated copy act(norm(u)): one extra write + the consumers read it as is.  Measured on the 32->16 conv at
+            // 128^3: transforming in the conv's staging loop costs +85 % of the kernel (VALU-bound, repeated for the
+            // 2.5x halo re-reads), the separate 2-pass copy ~0.03 ms.  288 GB of HBM makes the extra tensor free.
+            if (impl == UNET_IMPL_AUTO && (g.tensors[i].norm >= 0 || g.tensors[i].act != ACT_NONE))
+                a_off[i] = take((size_t)g.tensors[i].numel() * elsize);
         }
         n_stat.resize(g.norms.size()); n_coef.resize(g.norms.size());
         size_t pmax = 0;
@@ -189,12 +196,24 @@ struct Exec {
     float* coef(int n) const { return (float*)(ws + p.n_coef[n]); }
     float* partial() const { return (float*)(ws + p.partial_off); }
 
-    SrcDesc src(int t) const {
+    // the raw tensor with its recorded norm + activation applied by the reader
+    SrcDesc raw_src(int t) const {
         const Tensor& T = p.g.tensors[t];
         SrcDesc d;
         d.ptr = tptr(t); d.C = T.C; d.act = T.act;
         if (T.norm >= 0) { d.scale = stat(T.norm) + 2 * T.C; d.shift = stat(T.norm) + 3 * T.C; }
         return d;
+    }
+    // what consumers read: the activated copy when the plan keeps one (no per-read transform), else the raw tensor + transform
+    SrcDesc src(int t) const {
+        if (p.a_off[t] == SIZE_MAX) return raw_src(t);
+        SrcDesc d;
+        d.ptr = ws + p.a_off[t]; d.C = p.g.tensors[t].C;
+        return d;
+    }
+    // after the producer (and its norm statistics) are done: write the activated copy
+    void apply_view(int t) const {
+        if (p.a_off[t] != SIZE_MAX) launch_apply_view(p.dtype, raw_src(t), ws + p.a_off[t], p.g.tensors[t].voxels(), s);
     }
     ConvGeom geom(const Op& op) const {
         const Tensor& a = p.g.tensors[op.src[0]];
@@ -260,6 +279,7 @@ struct Exec {
                                              n.eps, stat(op.norm), n.batch ? buffers[n.buffer] : nullptr,
                                              n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, s);
                     }
+                    apply_view(n.tensor);
                     break;
                 }
                 case OP_MATERIALIZE: {
@@ -281,6 +301,11 @@ struct Exec {
                     if (outs && outs[op.out_level])
                         launch_export(p.dtype, src(op.src[0]), outs[op.out_level], g.tensors[op.src[0]].voxels(), s);
                     break;
+            }
+            // an activation recorded on a tensor that has no norm (e.g. "conv8,relu"): its copy is due right after the producer
+            if (op.kind != OP_NORM && op.kind != OP_EXPORT && op.dst >= 0) {
+                const Tensor& T = g.tensors[op.dst];
+                if (T.norm < 0 && T.act != ACT_NONE) apply_view(op.dst);
             }
         }
     }

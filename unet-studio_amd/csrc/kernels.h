@@ -93,6 +93,8 @@ void launch_maxpool_bwd(int dtype, SrcDesc src, const void* gout, DstGrad dst, i
 void launch_upsample_fwd(int dtype, SrcDesc src, void* out, int D, int H, int W, hipStream_t s);
 void launch_upsample_bwd(int dtype, const void* gout, DstGrad dst, int D, int H, int W, hipStream_t s);
 void launch_materialize(int dtype, const SrcDesc* src, int nsrc, void* out, int64_t S, hipStream_t s);
+// out = act(src*scale+shift) for a whole tensor (vectorised for bf16): the activated copy that consumers read
+void launch_apply_view(int dtype, SrcDesc src, void* out, int64_t S, hipStream_t s);
 void launch_materialize_bwd(int dtype, const void* gout, const DstGrad* dst, int ndst, int64_t S, hipStream_t s);
 void launch_export_bwd(int dtype, const float* g_ncdhw, DstGrad dst, int64_t S, hipStream_t s);
 void launch_unpack_ncdhw(int dtype, const void* g, float* out_ncdhw, int C, int64_t S, hipStream_t s);
