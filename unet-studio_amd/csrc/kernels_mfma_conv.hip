@@ -266,6 +266,215 @@ static void run_pack(const float* w, void* out, int Ci, int Co, int CK, int T, i
     k_mfma_pack<<<cdiv64(n, 256), 256, 0, s>>>(w, (__bf16*)out, Ci, Co, CK, T, mode, A, B);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of the kernel above (same maths, same arguments).  A block walks
+// tiles bid, bid + gridDim.x, ...; one pipeline stage = one (tile, channel chunk).  The global loads of
+// stage s+1 are issued into registers BEFORE the MFMAs of stage s and written to LDS after them, so HBM/L2
+// latency hides under the matrix work even at 2 blocks per CU (measured: the one-shot kernel spent ~6 % of
+// a block's lifetime in MFMAs, the rest waiting for the halo tile).
+// ------------------------------------------------------------------------------------------------
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
+__global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
+    constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD, NVOX = HZ * HY * HX;
+    constexpr int G = CK / 8;
+    constexpr int VS = CK == 32 ? 96 : 32;
+    constexpr int TXM = BX < 16 ? BX : 16;
+    constexpr int TYM = 16 / TXM;
+    constexpr int MT = BZ * BY * BX / 16, MTW = MT / 4;
+    constexpr int T = KD * KD * KD;
+    constexpr int KSTEPS = CK == 32 ? T : (T + 1) / 2;
+    constexpr int UNITS = NVOX * G, ITERS = (UNITS + 255) / 256;
+    static_assert(MT % 4 == 0 && MTW >= 1, "tile must give every wave at least one m-tile");
+    static_assert(ITERS <= 32, "in-bounds mask is one 32-bit word");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
+    const int nblk = a.tiles_x * a.tiles_y * a.tiles_z;
+    const int nt0 = blockIdx.y * NT, NTT = g.Cout / 16;
+    const int C0 = a.src[0].C;
+    const int lg = tid % G;
+    const int nchunk = g.Cin / CK;
+    const bf16x8* wp = (const bf16x8*)a.w;
+
+    int mz[MTW], my[MTW], mx[MTW], mbase[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        int mt = wave * MTW + i;
+        constexpr int RG = BY / TYM;
+        mz[i] = mt / RG; my[i] = (mt % RG) * TYM + (j / TXM); mx[i] = j % TXM;
+        mbase[i] = ((mz[i] * S * HY + my[i] * S) * HX + mx[i] * S) * VS + (CK == 32 ? gq : (gq & 1)) * 16;
+    }
+    f32x4 acc[MTW][NT];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // my tiles: k-th tile of this block is xcd_remap(blockIdx.x + k * gridDim.x)
+    const int my_tiles = nblk > (int)blockIdx.x ? (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nst = my_tiles * nchunk;
+
+    uint4 R[ITERS];
+    unsigned inb = 0;
+    // issue the global loads of stage st into R (no waiting)
+    auto prefetch = [&](int st) {
+        const int k = st / nchunk, q = st - k * nchunk;
+        const int bid = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, nblk);
+        const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
+        const int iz0 = z0 * S - PAD, iy0 = y0 * S - PAD, ix0 = x0 * S - PAD;
+        const int c = q * CK + lg * 8;
+        const int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
+        const SrcDesc& sd = a.src[s];
+        const char* base = (const char*)sd.ptr + (size_t)(c - (s ? C0 : 0)) * 2;
+        inb = 0;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int u = tid + it * 256;
+            const int hv = u / G;
+            const int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
+            const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+            R[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (u < UNITS && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                size_t vox = ((size_t)gz * g.H + gy) * g.W + gx;
+                R[it] = *(const uint4*)(base + vox * (size_t)sd.C * 2);
+                inb |= 1u << it;
+            }
+        }
+    };
+    // transform (if the source carries one) and write R to the LDS tile
+    auto commit = [&](int st) {
+        const int k = st / nchunk, q = st - k * nchunk;
+        const int c = q * CK + lg * 8;
+        const int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
+        const SrcDesc& sd = a.src[s];
+        const int cl = c - (s ? C0 : 0);
+        const bool xf = sd.scale != nullptr;
+        const int act = sd.act;
+        float sc[8], sh[8];
+        if (xf) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = sd.scale[cl + e]; sh[e] = sd.shift[cl + e]; }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int u = tid + it * 256;
+            if (u < UNITS) {
+                uint4 v = R[it];
+                if ((xf || act) && ((inb >> it) & 1u)) v = transform8(v, xf, sc, sh, act);
+                *(uint4*)(smem + (u / G) * VS + lg * 16) = v;
+            }
+        }
+    };
+
+    if (nst > 0) prefetch(0);
+    for (int st = 0; st < nst; ++st) {
+        const int k = st / nchunk, q = st - k * nchunk;
+        __syncthreads();                 // every wave is done reading the previous stage's tile
+        commit(st);
+        __syncthreads();
+        if (st + 1 < nst) prefetch(st + 1);   // in flight during the MFMAs below
+
+        const bf16x8* wq = wp + ((size_t)q * KSTEPS * NTT + nt0) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            bf16x8 wf[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wf[n] = wq[((size_t)ks * NTT + n) * 64];
+            int toff;
+            if (CK == 32) {
+                toff = (((ks / (KD * KD)) * HY + (ks / KD) % KD) * HX + ks % KD) * VS;
+            } else {
+                const int t0 = 2 * ks, t1 = 2 * ks + 1 < T ? 2 * ks + 1 : 2 * ks;
+                const int o0 = (((t0 / (KD * KD)) * HY + (t0 / KD) % KD) * HX + t0 % KD) * VS;
+                const int o1 = (((t1 / (KD * KD)) * HY + (t1 / KD) % KD) * HX + t1 % KD) * VS;
+                toff = (lane & 32) ? o1 : o0;
+            }
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                bf16x8 xb = *(const bf16x8*)(smem + mbase[i] + toff);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xb, acc[i][n], 0, 0, 0);
+            }
+        }
+        if (q != nchunk - 1) continue;
+
+        // ---- tile epilogue ----
+        const int bid = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, nblk);
+        const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
+        float s1[NT][4], s2[NT][4];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int c = (nt0 + n) * 16 + gq * 4;
+            int tz = 0, ty = 0, tx = 0;
+            if (SC) { int tap = c / a.sc_C; c -= tap * a.sc_C; tz = tap >> 2; ty = (tap >> 1) & 1; tx = tap & 1; }
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[r] = a.bias[c + r];
+            }
+            int d = (a.nout > 1 && c >= a.outC[0]) ? 1 : 0;
+            int cd = c - (d ? a.outC[0] : 0);
+            char* obase = (char*)a.out[d];
+            const int oC = a.outC[d], oacc = a.out_acc[d];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) {
+                int gz = z0 + mz[i], gy = y0 + my[i], gx = x0 + mx[i];
+                if (SC) { gz = 2 * gz + tz; gy = 2 * gy + ty; gx = 2 * gx + tx; }
+                if (gz < a.oD && gy < a.oH && gx < a.oW && obase) {
+                    size_t vox = ((size_t)gz * a.oH + gy) * a.oW + gx;
+                    uint2* p = (uint2*)(obase + (vox * oC + cd) * 2);
+                    float v0 = acc[i][n][0] + b4[0], v1 = acc[i][n][1] + b4[1], v2 = acc[i][n][2] + b4[2], v3 = acc[i][n][3] + b4[3];
+                    if (oacc) {
+                        uint2 old = *p;
+                        v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                    *p = o;
+                    if (!SC && a.stats) {
+                        float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
+                        s1[n][0] += r0; s1[n][1] += r1; s1[n][2] += r2; s1[n][3] += r3;
+                        s2[n][0] = fmaf(r0, r0, s2[n][0]); s2[n][1] = fmaf(r1, r1, s2[n][1]);
+                        s2[n][2] = fmaf(r2, r2, s2[n][2]); s2[n][3] = fmaf(r3, r3, s2[n][3]);
+                    }
+                }
+                acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (!SC && a.stats) {
+            float* red = (float*)smem;
+            __syncthreads();                          // tile no longer needed (the next commit syncs again before writing)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float u = s1[n][r], v = s2[n][r];
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+                    if (j == 0) {
+                        int cl = n * 16 + gq * 4 + r;
+                        red[(wave * NT * 16 + cl) * 2 + 0] = u;
+                        red[(wave * NT * 16 + cl) * 2 + 1] = v;
+                    }
+                }
+            __syncthreads();
+            if (tid < NT * 16) {
+                float u = 0.f, v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
+                int c = nt0 * 16 + tid;
+                a.stats[((size_t)bid * g.Cout + c) * 2 + 0] = u;
+                a.stats[((size_t)bid * g.Cout + c) * 2 + 1] = v;
+            }
+        }
+    }
+}
+
 // ---- launch plumbing ----
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
 static void launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
@@ -277,11 +486,17 @@ static void launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_conv<S, KD, PAD, BZ, BY, BX, CK, NT, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.tiles_z), (unsigned)(a.g.Cout / (16 * NT)));
-    k_mfma_conv<S, KD, PAD, BZ, BY, BX, CK, NT, SC><<<grid, 256, lds, s>>>(a);
+    // persistent grid: at most ~2 blocks per CU in total (256 CUs), tiles strided over them
+    const int tiles = a.tiles_x * a.tiles_y * a.tiles_z, gy = a.g.Cout / (16 * NT);
+    constexpr int bpc = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : 2);   // resident blocks per CU the LDS tile allows (cap 4)
+    int gx = bpc * 256 / gy;
+    if (gx < 1) gx = 1;
+    if (gx > tiles) gx = tiles;
+    dim3 grid((unsigned)gx, (unsigned)gy);
+    k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC><<<grid, 256, lds, s>>>(a);
 }
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> static void launch_nt(const MfmaConvArgs& a, hipStream_t s) {
     int ntt = a.g.Cout / 16;
