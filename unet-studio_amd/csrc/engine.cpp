@@ -59,6 +59,11 @@ struct unet_plan {
     size_t ws_bytes = 0;
     // loss scratch layout
     size_t loss_bytes = 0;
+    // batched MFMA filter pack (used when the caller's parameters are one flat contiguous buffer)
+    std::vector<int64_t> p_off;              // element offset of parameter i in a flat buffer
+    std::vector<PackJob> pack_jobs;
+    int64_t pack_blocks = 0;
+    PackJob* jobs_dev = nullptr;
     // sgd
     SgdSeg* segs_dev = nullptr;
     int nseg = 0;
@@ -66,6 +71,7 @@ struct unet_plan {
 
     ~unet_plan() {
         if (segs_dev) (void)hipFree(segs_dev);
+        if (jobs_dev) (void)hipFree(jobs_dev);
     }
 
     ConvGeom op_geom_of(const Op& op) const {
@@ -179,6 +185,28 @@ struct unet_plan {
         }
         wgrad_off = take(wmax ? wmax : 256);
         ws_bytes = off;
+        // batched filter pack: one job per MFMA filter pack, sources as offsets into a flat parameter buffer
+        p_off.assign(g.params.size() + 1, 0);
+        for (size_t i = 0; i < g.params.size(); ++i) {
+            int64_t n = 1;
+            for (auto d : g.params[i].shape) n *= d;
+            p_off[i + 1] = p_off[i] + n;
+        }
+        pack_jobs.clear();
+        pack_blocks = 0;
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if ((op.kind != OP_CONV && op.kind != OP_CONVT) || !use_mfma[i]) continue;
+            PackJob jb[2];
+            int n = op.kind == OP_CONV ? mfma_conv_pack_jobs(op_geom_of(op), dgrad_mfma[i] != 0, jb) : mfma_convt_pack_jobs(op_geom_of(op), jb);
+            for (int k = 0; k < n; ++k) {
+                jb[k].src_off = p_off[op.weight];
+                jb[k].dst_off = (int64_t)(k == 0 ? wm_fwd[i] : wm_dgrad[i]);
+                jb[k].blk0 = pack_blocks;
+                pack_blocks += (jb[k].total + 255) / 256;
+                pack_jobs.push_back(jb[k]);
+            }
+        }
     }
 };
 
@@ -227,6 +255,16 @@ struct Exec {
     void forward(const float* const* params, float* const* buffers, const float* x, float* const* outs, int mode) {
         const Graph& g = p.g;
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
+        // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
+        bool packed = false;
+        if (p.jobs_dev) {
+            bool flat = true;
+            for (size_t i = 0; i < g.params.size() && flat; ++i) flat = params[i] == params[0] + p.p_off[i];
+            if (flat) {
+                launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, s);
+                packed = true;
+            }
+        }
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             switch (op.kind) {
@@ -241,8 +279,9 @@ struct Exec {
                     float* wf = (float*)(ws + p.w_fwd[i]);
                     float* wd = (float*)(ws + p.w_dgrad[i]);
                     if (op.kind == OP_CONV && p.use_mfma[i]) {
-                        launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i],
-                                                (mode == 1 && p.dgrad_mfma[i]) ? ws + p.wm_dgrad[i] : nullptr, cg, s);
+                        if (!packed)
+                            launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i],
+                                                    (mode == 1 && p.dgrad_mfma[i]) ? ws + p.wm_dgrad[i] : nullptr, cg, s);
                         if (mode == 1 && !p.dgrad_mfma[i])
                             launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         const Tensor& T = g.tensors[op.dst];
@@ -255,7 +294,7 @@ struct Exec {
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
                                                op.out_level >= 0 ? outs[op.out_level] : nullptr, s);
                     } else if (p.use_mfma[i]) {
-                        launch_mfma_pack_convt_w(params[op.weight], ws + p.wm_fwd[i], mode == 1 ? ws + p.wm_dgrad[i] : nullptr, cg, s);
+                        if (!packed) launch_mfma_pack_convt_w(params[op.weight], ws + p.wm_fwd[i], mode == 1 ? ws + p.wm_dgrad[i] : nullptr, cg, s);
                         launch_mfma_convt_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst), s);
                     } else {
                         launch_pack_convt_w(params[op.weight], wf, wd, op.cin, op.cout, s);
@@ -318,7 +357,7 @@ struct Exec {
             launch_norm_bwd_partial(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), T.act, partial(), s);
             launch_norm_bwd_finalize(partial(), stats_blocks(T.voxels()), T.C, T.voxels(), params[n.gamma], stat(T.norm), coef(T.norm),
                                      gparams[n.gamma], gparams[n.beta], s);
-            launch_norm_bwd_apply(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), coef(T.norm), s);
+            launch_norm_bwd_apply(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), coef(T.norm), T.act, s);
         } else if (T.act != ACT_NONE) {
             launch_act_bwd(p.dtype, gptr(t), tptr(t), T.act, T.numel(), s);
         }
@@ -490,6 +529,10 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
             DeviceGuard dg(device);
             HIP_OK(hipMalloc((void**)&p->segs_dev, segs.size() * sizeof(SgdSeg)));
             HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
+            if (!p->pack_jobs.empty()) {
+                HIP_OK(hipMalloc((void**)&p->jobs_dev, p->pack_jobs.size() * sizeof(PackJob)));
+                HIP_OK(hipMemcpy(p->jobs_dev, p->pack_jobs.data(), p->pack_jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+            }
         }
         *out = p;
         return 0;

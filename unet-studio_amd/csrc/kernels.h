@@ -85,7 +85,8 @@ void launch_norm_bwd_partial(int dtype, void* g, const void* u, int C, int64_t S
 void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat, float* coef,
                               float* dgamma, float* dbeta, hipStream_t s);
 // pass 3: g <- du = coef0 * (dv - m1 - xhat*m2)
-void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, hipStream_t s);
+void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, int act,
+                           hipStream_t s);
 
 // ---- pooling / resampling / copies ----
 void launch_maxpool_fwd(int dtype, SrcDesc src, void* out, int D, int H, int W, hipStream_t s);
@@ -118,7 +119,13 @@ void launch_sgd(float* p, float* g, float* m, int64_t n, const SgdSeg* segs_dev,
                 float lr, float momentum, int nesterov, float weight_decay, float clip_norm, float grad_scale, float* norm_out,
                 hipStream_t s);
 
-// ---- MFMA implicit-GEMM family (kernels_mfma.hip), bf16 only ----
+// ---- MFMA implicit-GEMM family (kernels_mfma_conv.hip, kernels_mfma_wgrad.hip), bf16 only ----
+// one filter pack of the batched pack kernel: fp32 parameter (src_off floats from the flat parameter base) ->
+// bf16 fragments at dst_off bytes into the workspace; blk0 = first 256-thread block of the job in the launch
+struct PackJob { int64_t src_off, dst_off, total, blk0; int Ci, Co, CK, T, mode, A, B, pad; };
+int mfma_conv_pack_jobs(const ConvGeom& g, bool want_dgrad, PackJob* out2);
+int mfma_convt_pack_jobs(const ConvGeom& g, PackJob* out2);
+void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s);
 bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_conv_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);

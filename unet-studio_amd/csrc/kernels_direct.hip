@@ -112,8 +112,46 @@ template <typename T> __global__ void __launch_bounds__(256) k_conv_fwd_direct(C
     }
 }
 
+// Cin = 1, 3x3x3 stride 1 (the network's first conv): one thread = one voxel x ALL output channels (<= 32), the 27
+// neighbours are loaded once, the filter sits in LDS.  HBM-bound on the 2*Cout bytes per voxel it writes.
+template <typename T, int CO> __global__ void __launch_bounds__(256) k_conv_first(ConvFwdArgs a) {
+    __shared__ float sw[27 * CO + CO];
+    const ConvGeom& g = a.g;
+    const int CoutP = round_up(g.Cout, 8);
+    for (int i = threadIdx.x; i < 27 * CO; i += 256) { int t = i / CO, c = i % CO; sw[i] = c < g.Cout ? a.w[(int64_t)t * CoutP + c] : 0.f; }
+    for (int i = threadIdx.x; i < CO; i += 256) sw[27 * CO + i] = (a.bias && i < g.Cout) ? a.bias[i] : 0.f;
+    __syncthreads();
+    int64_t S = (int64_t)g.D * g.H * g.W;
+    int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= S) return;
+    int x = (int)(v % g.W); int64_t r = v / g.W;
+    int y = (int)(r % g.H); int z = (int)(r / g.H);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = sw[27 * CO + c];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+        int iz = z + t / 9 - 1, iy = y + (t / 3) % 3 - 1, ix = x + t % 3 - 1;
+        float xv = 0.f;
+        if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) xv = view_ld<T>(a.src[0], ((int64_t)iz * g.H + iy) * g.W + ix, 0);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, sw[t * CO + c], acc[c]);
+    }
+    T* o = (T*)a.out + v * g.Cout;
+    for (int c = 0; c < CO; ++c)
+        if (c < g.Cout) st<T>(o, c, acc[c]);
+}
+
 void launch_conv_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w, const float* bias,
                             void* out, float* out_ncdhw, hipStream_t s) {
+    if (g.Cin == 1 && nsrc == 1 && g.ks == 3 && g.stride == 1 && g.Cout <= 32 && !out_ncdhw) {
+        ConvFwdArgs f;
+        f.g = g; f.nsrc = 1; f.src[0] = src[0]; f.w = w; f.bias = bias; f.out = out; f.out_ncdhw = nullptr;
+        int64_t S = (int64_t)g.D * g.H * g.W;
+        if (g.Cout <= 16) { UNET_DISPATCH(dtype, (k_conv_first<T, 16><<<cdiv64(S, 256), 256, 0, s>>>(f))); }
+        else { UNET_DISPATCH(dtype, (k_conv_first<T, 32><<<cdiv64(S, 256), 256, 0, s>>>(f))); }
+        return;
+    }
     ConvFwdArgs a;
     a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
     a.w = w; a.bias = bias; a.out = out; a.out_ncdhw = out_ncdhw;

@@ -53,14 +53,13 @@ void launch_export_bwd(int dtype, const float* g, DstGrad dst, int64_t S, hipStr
 // ------------------------------------------------------------------------------------------------
 // norm statistics.  Block b covers voxels [b*VPB, (b+1)*VPB); threads = (voxel lane) x (channel).
 // ------------------------------------------------------------------------------------------------
-int stats_blocks(int64_t S) {
-    int64_t vpb = (S + 1023) / 1024;
-    if (vpb < 256) vpb = 256;
-    return (int)((S + vpb - 1) / vpb);
-}
 static inline int64_t stats_vpb(int64_t S) {
     int64_t vpb = (S + 1023) / 1024;
-    return vpb < 256 ? 256 : vpb;
+    return vpb < 32 ? 32 : vpb;          // small (deep-level) tensors still get up to S/32 blocks
+}
+int stats_blocks(int64_t S) {
+    int64_t vpb = stats_vpb(S);
+    return (int)((S + vpb - 1) / vpb);
 }
 static inline int pow2_ge(int c) { int p = 1; while (p < c && p < 256) p <<= 1; return p; }
 
@@ -80,11 +79,8 @@ __global__ void __launch_bounds__(256) k_stats_partial(const T* __restrict__ x, 
             for (int64_t v = v0 + lane; v < v1; v += NV) {
                 float u = ld<T>(x, v * C + c);
                 if (MODE == 0) { s1 += u; s2 = fmaf(u, u, s2); }
-                else {
+                else {   // dv is not stored: the apply pass recomputes it from the same inputs
                     float dv = ld<T>(gbuf, v * C + c) * act_d(fmaf(u, sc, sh), act);
-                    st<T>(gbuf, v * C + c, dv);
-                    // statistics of the value the apply pass will read back (rounded to T)
-                    dv = ld<T>(gbuf, v * C + c);
                     s1 += dv; s2 = fmaf(dv, (u - mean) * rstd, s2);
                 }
             }
@@ -104,9 +100,80 @@ void launch_stats_partial(int dtype, const void* x, int C, int64_t S, float* par
     int nb = stats_blocks(S);
     UNET_DISPATCH(dtype, (k_stats_partial<T, 0><<<nb, 256, 0, s>>>((const T*)x, nullptr, C, S, stats_vpb(S), pow2_ge(C), nullptr, 0, partial)));
 }
+// bf16, C/8 a power of two <= 256: 16 B (8 channels) per load.  thread = (voxel lane, 8-channel group).
+__device__ __forceinline__ void unpack8(uint4 v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__global__ void __launch_bounds__(256) k_norm_bwd_stats8(const uint4* __restrict__ u8, const uint4* __restrict__ g8, int C, int64_t S,
+                                                         int64_t VPB, const float* __restrict__ stat, int act, float* __restrict__ partial) {
+    __shared__ float red[256][17];
+    const int G8 = C / 8, NV = 256 / G8, grp = threadIdx.x % G8, lane = threadIdx.x / G8, c0 = grp * 8;
+    const int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
+    float mean[8], rstd[8], sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mean[e] = stat[c0 + e]; rstd[e] = stat[C + c0 + e]; sc[e] = stat[2 * C + c0 + e]; sh[e] = stat[3 * C + c0 + e];
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    for (int64_t v = v0 + lane; v < v1; v += NV) {
+        float uf[8], gf[8];
+        unpack8(u8[v * G8 + grp], uf);
+        unpack8(g8[v * G8 + grp], gf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float dv = gf[e] * act_d(fmaf(uf[e], sc[e], sh[e]), act);
+            s1[e] += dv; s2[e] = fmaf(dv, (uf[e] - mean[e]) * rstd[e], s2[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < G8 * 8) {
+        const int gg = threadIdx.x / 8, e = threadIdx.x % 8;
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < NV; ++l) { a += red[l * G8 + gg][e]; b += red[l * G8 + gg][8 + e]; }
+        partial[((int64_t)blockIdx.x * C + gg * 8 + e) * 2 + 0] = a;
+        partial[((int64_t)blockIdx.x * C + gg * 8 + e) * 2 + 1] = b;
+    }
+}
+__global__ void __launch_bounds__(256) k_norm_bwd_apply8(uint4* __restrict__ g8, const uint4* __restrict__ u8, int C, int64_t n8,
+                                                         const float* __restrict__ stat, const float* __restrict__ coef, int act) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const int c0 = (int)((i * 8) % C);
+    float uf[8], gf[8];
+    unpack8(u8[i], uf);
+    unpack8(g8[i], gf);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        float r[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = c0 + e + k;
+            float dv = gf[e + k] * act_d(fmaf(uf[e + k], stat[2 * C + c], stat[3 * C + c]), act);
+            float xh = (uf[e + k] - stat[c]) * stat[C + c];
+            r[k] = coef[c] * (dv - coef[C + c] - xh * coef[2 * C + c]);
+        }
+        w[e / 2] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(r[0])) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(r[1])) << 16);
+    }
+    g8[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+static inline bool vec8_ok(int dtype, int C) {
+    if (dtype != 1 || C % 8) return false;
+    int g8 = C / 8;
+    return g8 <= 256 && (g8 & (g8 - 1)) == 0;
+}
 void launch_norm_bwd_partial(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, int act, float* partial,
                              hipStream_t s) {
     int nb = stats_blocks(S);
+    if (vec8_ok(dtype, C)) {
+        k_norm_bwd_stats8<<<nb, 256, 0, s>>>((const uint4*)u, (const uint4*)g, C, S, stats_vpb(S), stat, act, partial);
+        return;
+    }
     UNET_DISPATCH(dtype, (k_stats_partial<T, 1><<<nb, 256, 0, s>>>((const T*)u, (T*)g, C, S, stats_vpb(S), pow2_ge(C), stat, act, partial)));
 }
 
@@ -181,15 +248,23 @@ void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, 
 }
 
 template <typename T> __global__ void k_norm_bwd_apply(T* __restrict__ g, const T* __restrict__ u, int C, int64_t n,
-                                                       const float* __restrict__ stat, const float* __restrict__ coef) {
+                                                       const float* __restrict__ stat, const float* __restrict__ coef, int act) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     int c = (int)(i % C);
-    float xh = (ld<T>(u, i) - stat[c]) * stat[C + c];
-    st<T>(g, i, coef[c] * (ld<T>(g, i) - coef[C + c] - xh * coef[2 * C + c]));
+    float uu = ld<T>(u, i);
+    float dv = ld<T>(g, i) * act_d(fmaf(uu, stat[2 * C + c], stat[3 * C + c]), act);
+    float xh = (uu - stat[c]) * stat[C + c];
+    st<T>(g, i, coef[c] * (dv - coef[C + c] - xh * coef[2 * C + c]));
 }
-void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, hipStream_t s) {
-    UNET_DISPATCH(dtype, (k_norm_bwd_apply<T><<<cdiv64(S * C, 256), 256, 0, s>>>((T*)g, (const T*)u, C, S * C, stat, coef)));
+void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, int act,
+                           hipStream_t s) {
+    if (vec8_ok(dtype, C)) {
+        int64_t n8 = S * C / 8;
+        k_norm_bwd_apply8<<<cdiv64(n8, 256), 256, 0, s>>>((uint4*)g, (const uint4*)u, C, n8, stat, coef, act);
+        return;
+    }
+    UNET_DISPATCH(dtype, (k_norm_bwd_apply<T><<<cdiv64(S * C, 256), 256, 0, s>>>((T*)g, (const T*)u, C, S * C, stat, coef, act)));
 }
 
 template <typename T> __global__ void k_act_bwd(T* __restrict__ g, const T* __restrict__ u, int act, int64_t n) {

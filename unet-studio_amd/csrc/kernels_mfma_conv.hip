@@ -220,10 +220,10 @@ enum PackMode {
     PK_CONV_S2_DGRAD = 4 // rows o = p*A + ci (p = output parity), i = cout, 8 taps k in {0,1}^3 over dy[m+k]:
                         //   per dim  p=0: k=0 -> filter tap 1 ;  p=1: k=0 -> tap 2, k=1 -> tap 0 ; else zero     A = Cin
 };
-__global__ void k_mfma_pack(const float* __restrict__ w, __bf16* __restrict__ out, int Ci, int Co, int CK, int T, int mode, int A, int B) {
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, __bf16* __restrict__ out, int64_t idx, int Ci, int Co, int CK, int T,
+                                         int mode, int A, int B) {
     int KSTEPS = CK == 32 ? T : (T + 1) / 2, NTT = Co / 16;
     int64_t total = (int64_t)(Ci / CK) * KSTEPS * NTT * 64 * 8;
-    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     int e = (int)(idx & 7); int64_t r = idx >> 3;
     int lane = (int)(r & 63); r >>= 6;
@@ -255,11 +255,36 @@ __global__ void k_mfma_pack(const float* __restrict__ w, __bf16* __restrict__ ou
     }
     out[idx] = (__bf16)v;
 }
+__global__ void k_mfma_pack(const float* __restrict__ w, __bf16* __restrict__ out, int Ci, int Co, int CK, int T, int mode, int A, int B) {
+    pack_one(w, out, (int64_t)blockIdx.x * 256 + threadIdx.x, Ci, Co, CK, T, mode, A, B);
+}
+// every filter pack of a plan in ONE launch: block -> job by binary search over the jobs' first block index
+__global__ void __launch_bounds__(256) k_mfma_pack_batched(const float* __restrict__ params_base, char* __restrict__ ws,
+                                                           const PackJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob jb = jobs[lo];
+    pack_one(params_base + jb.src_off, (__bf16*)(ws + jb.dst_off), ((int64_t)blockIdx.x - jb.blk0) * 256 + threadIdx.x, jb.Ci, jb.Co,
+             jb.CK, jb.T, jb.mode, jb.A, jb.B);
+}
+void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s) {
+    if (njobs > 0) k_mfma_pack_batched<<<(unsigned)nblocks, 256, 0, s>>>(params_base, (char*)ws, jobs_dev, njobs);
+}
 
 static inline int pick_ck(int Ci, bool allow32) { return (allow32 && Ci % 32 == 0) ? 32 : 16; }
 static size_t pack_bytes(int Ci, int Co, int CK, int T) {
     int KSTEPS = CK == 32 ? T : (T + 1) / 2;
     return (size_t)(Ci / CK) * KSTEPS * (Co / 16) * 64 * 16;
+}
+static PackJob make_job(int Ci, int Co, int CK, int T, int mode, int A, int B) {
+    PackJob j;
+    j.src_off = 0; j.dst_off = 0; j.blk0 = 0;
+    j.Ci = Ci; j.Co = Co; j.CK = CK; j.T = T; j.mode = mode; j.A = A; j.B = B; j.pad = 0;
+    j.total = (int64_t)pack_bytes(Ci, Co, CK, T) / 2;
+    return j;
 }
 static void run_pack(const float* w, void* out, int Ci, int Co, int CK, int T, int mode, int A, int B, hipStream_t s) {
     int64_t n = (int64_t)pack_bytes(Ci, Co, CK, T) / 2;
@@ -595,6 +620,14 @@ void launch_mfma_pack_conv_w(const float* w, void* w_fwd, void* w_dgrad, const C
         else run_pack(w, w_dgrad, g.Cout, 8 * g.Cin, 32, 8, PK_CONV_S2_DGRAD, g.Cin, g.Cout, s);
     }
 }
+// the same packs as launch_mfma_pack_conv_w, described for the batched pack kernel: out[0] forward, out[1] dgrad
+int mfma_conv_pack_jobs(const ConvGeom& g, bool want_dgrad, PackJob* out) {
+    out[0] = make_job(g.Cin, g.Cout, fwd_ck(g), 27, PK_CONV_FWD, g.Cin, g.Cout);
+    if (!want_dgrad) return 1;
+    if (g.stride == 1) out[1] = make_job(g.Cout, g.Cin, pick_ck(g.Cout, true), 27, PK_CONV_DGRAD, g.Cin, g.Cout);
+    else out[1] = make_job(g.Cout, 8 * g.Cin, 32, 8, PK_CONV_S2_DGRAD, g.Cin, g.Cout);
+    return 2;
+}
 int mfma_conv_blocks(const ConvGeom& g) {
     Tile t = g.stride == 1 ? tile_s1k3(g, fwd_ck(g)) : tile_s2k3(g.Wo);
     return tile_count(g, t);
@@ -637,6 +670,11 @@ size_t mfma_convt_dgrad_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cout, g
 void launch_mfma_pack_convt_w(const float* w, void* w_fwd, void* w_dgrad, const ConvGeom& g, hipStream_t s) {
     if (w_fwd) run_pack(w, w_fwd, g.Cin, 8 * g.Cout, 32, 1, PK_CONVT_FWD, g.Cin, g.Cout, s);
     if (w_dgrad) run_pack(w, w_dgrad, g.Cout, g.Cin, 16, 8, PK_CONVT_DGRAD, g.Cin, g.Cout, s);
+}
+int mfma_convt_pack_jobs(const ConvGeom& g, PackJob* out) {
+    out[0] = make_job(g.Cin, 8 * g.Cout, 32, 1, PK_CONVT_FWD, g.Cin, g.Cout);
+    out[1] = make_job(g.Cout, g.Cin, 16, 8, PK_CONVT_DGRAD, g.Cin, g.Cout);
+    return 2;
 }
 void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s) {
     MfmaConvArgs a = base_args();
