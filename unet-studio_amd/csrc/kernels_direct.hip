@@ -115,12 +115,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_conv_fwd_direct(C
 // Cin = 1, 3x3x3 stride 1 (the network's first conv): one thread = one voxel x ALL output channels (<= 32), the 27
 // neighbours are loaded once, the filter sits in LDS.  HBM-bound on the 2*Cout bytes per voxel it writes.
 template <typename T, int CO> __global__ void __launch_bounds__(256) k_conv_first(ConvFwdArgs a) {
-    __shared__ float sw[27 * CO + CO];
     const ConvGeom& g = a.g;
-    const int CoutP = round_up(g.Cout, 8);
-    for (int i = threadIdx.x; i < 27 * CO; i += 256) { int t = i / CO, c = i % CO; sw[i] = c < g.Cout ? a.w[(int64_t)t * CoutP + c] : 0.f; }
-    for (int i = threadIdx.x; i < CO; i += 256) sw[27 * CO + i] = (a.bias && i < g.Cout) ? a.bias[i] : 0.f;
-    __syncthreads();
+    const int CoutP = round_up(g.Cout, 8);   // packed filter [27][CoutP]: wave-uniform addresses -> scalar loads
     int64_t S = (int64_t)g.D * g.H * g.W;
     int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (v >= S) return;
@@ -128,18 +124,34 @@ template <typename T, int CO> __global__ void __launch_bounds__(256) k_conv_firs
     int y = (int)(r % g.H); int z = (int)(r / g.H);
     float acc[CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = sw[27 * CO + c];
+    for (int c = 0; c < CO; ++c) acc[c] = (a.bias && c < g.Cout) ? a.bias[c] : 0.f;
 #pragma unroll
     for (int t = 0; t < 27; ++t) {
         int iz = z + t / 9 - 1, iy = y + (t / 3) % 3 - 1, ix = x + t % 3 - 1;
         float xv = 0.f;
         if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) xv = view_ld<T>(a.src[0], ((int64_t)iz * g.H + iy) * g.W + ix, 0);
+        const float* wr = a.w + (int64_t)t * CoutP;
 #pragma unroll
-        for (int c = 0; c < CO; ++c) acc[c] = fmaf(xv, sw[t * CO + c], acc[c]);
+        for (int c = 0; c < CO; ++c)
+            if (c < CoutP) acc[c] = fmaf(xv, wr[c], acc[c]);
     }
     T* o = (T*)a.out + v * g.Cout;
-    for (int c = 0; c < CO; ++c)
-        if (c < g.Cout) st<T>(o, c, acc[c]);
+    if (sizeof(T) == 2 && g.Cout % 8 == 0) {   // 16-B stores
+#pragma unroll
+        for (int c = 0; c < CO; c += 8) {
+            if (c < g.Cout) {
+                unsigned w4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    w4[e] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[c + 2 * e])) |
+                            ((unsigned)__bfloat16_as_ushort(__float2bfloat16(acc[c + 2 * e + 1])) << 16);
+                *(uint4*)((char*)o + c * 2) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+        }
+    } else {
+        for (int c = 0; c < CO; ++c)
+            if (c < g.Cout) st<T>(o, c, acc[c]);
+    }
 }
 
 void launch_conv_fwd_direct(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w, const float* bias,

@@ -139,28 +139,35 @@ __global__ void __launch_bounds__(256) k_norm_bwd_stats8(const uint4* __restrict
         partial[((int64_t)blockIdx.x * C + gg * 8 + e) * 2 + 1] = b;
     }
 }
-__global__ void __launch_bounds__(256) k_norm_bwd_apply8(uint4* __restrict__ g8, const uint4* __restrict__ u8, int C, int64_t n8,
+// same thread geometry as k_norm_bwd_stats8: a thread keeps its 8 channels' coefficients in registers and walks voxels.
+// du = A*da*act'(v) + B*u + D   with  A = coef0, B = -coef0*rstd*m2, D = -coef0*(m1 - mean*rstd*m2)
+__global__ void __launch_bounds__(256) k_norm_bwd_apply8(uint4* __restrict__ g8, const uint4* __restrict__ u8, int C, int64_t S, int64_t VPB,
                                                          const float* __restrict__ stat, const float* __restrict__ coef, int act) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n8) return;
-    const int c0 = (int)((i * 8) % C);
-    float uf[8], gf[8];
-    unpack8(u8[i], uf);
-    unpack8(g8[i], gf);
-    unsigned w[4];
+    const int G8 = C / 8, NV = 256 / G8, grp = threadIdx.x % G8, lane = threadIdx.x / G8, c0 = grp * 8;
+    const int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
+    float sc[8], sh[8], A[8], B[8], D[8];
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        float r[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = c0 + e + k;
-            float dv = gf[e + k] * act_d(fmaf(uf[e + k], stat[2 * C + c], stat[3 * C + c]), act);
-            float xh = (uf[e + k] - stat[c]) * stat[C + c];
-            r[k] = coef[c] * (dv - coef[C + c] - xh * coef[2 * C + c]);
-        }
-        w[e / 2] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(r[0])) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(r[1])) << 16);
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const float mean = stat[c], rstd = stat[C + c];
+        sc[e] = stat[2 * C + c]; sh[e] = stat[3 * C + c];
+        A[e] = coef[c];
+        B[e] = -coef[c] * rstd * coef[2 * C + c];
+        D[e] = -coef[c] * (coef[C + c] - mean * rstd * coef[2 * C + c]);
     }
-    g8[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int64_t v = v0 + lane; v < v1; v += NV) {
+        float uf[8], gf[8];
+        unpack8(u8[v * G8 + grp], uf);
+        unpack8(g8[v * G8 + grp], gf);
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float r0 = fmaf(A[e] * gf[e], act_d(fmaf(uf[e], sc[e], sh[e]), act), fmaf(B[e], uf[e], D[e]));
+            float r1 = fmaf(A[e + 1] * gf[e + 1], act_d(fmaf(uf[e + 1], sc[e + 1], sh[e + 1]), act), fmaf(B[e + 1], uf[e + 1], D[e + 1]));
+            w[e / 2] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(r0)) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(r1)) << 16);
+        }
+        g8[v * G8 + grp] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
 }
 static inline bool vec8_ok(int dtype, int C) {
     if (dtype != 1 || C % 8) return false;
@@ -260,8 +267,9 @@ template <typename T> __global__ void k_norm_bwd_apply(T* __restrict__ g, const 
 void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, int act,
                            hipStream_t s) {
     if (vec8_ok(dtype, C)) {
-        int64_t n8 = S * C / 8;
-        k_norm_bwd_apply8<<<cdiv64(n8, 256), 256, 0, s>>>((uint4*)g, (const uint4*)u, C, n8, stat, coef, act);
+        int64_t vpb = (S + 4095) / 4096;          // up to 4096 blocks, each a contiguous voxel range
+        if (vpb < 32) vpb = 32;
+        k_norm_bwd_apply8<<<cdiv64(S, vpb), 256, 0, s>>>((uint4*)g, (const uint4*)u, C, S, vpb, stat, coef, act);
         return;
     }
     UNET_DISPATCH(dtype, (k_norm_bwd_apply<T><<<cdiv64(S * C, 256), 256, 0, s>>>((T*)g, (const T*)u, C, S * C, stat, coef, act)));
