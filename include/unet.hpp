@@ -1,0 +1,133 @@
+// Drop-in replacement for the reference's unet.hpp (unet.hpp:1-73): the same `UNet3dImpl` / `UNet3d`
+// operator surface -- public fields, method names, signatures and error behaviour -- over libunet_hip.so.
+// train.cpp, evaluate.cpp, qc.cpp, main.cpp and the Qt front-end compile against it unchanged; the
+// implementation (unet-studio_amd/csrc/unet_host.cpp) replaces unet.cpp and drives the HIP engine through the
+// C ABI of unet_hip.h instead of building torch::nn conv/norm modules.
+#ifndef UNET_HPP
+#define UNET_HPP
+#ifdef QT_CORE_LIB
+    #undef slots
+#endif
+#include <torch/torch.h>
+#ifdef QT_CORE_LIB
+    #define slots Q_SLOTS
+#endif
+#include <array>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#if __has_include("TIPL/tipl.hpp")
+#include "TIPL/tipl.hpp"
+namespace unet_types { typedef tipl::vector<3> vector3; typedef tipl::shape<3> shape3; }
+#else
+// TIPL is not vendored with the reference; without it the two geometry fields fall back to plain PODs with the
+// operations this class needs (indexing, streaming).  With TIPL on the include path the TIPL types are used.
+namespace unet_types {
+struct vector3 {
+    float v[3];
+    vector3(float x = 1.f, float y = 1.f, float z = 1.f) : v{x, y, z} {}
+    float& operator[](size_t i) { return v[i]; }
+    const float& operator[](size_t i) const { return v[i]; }
+};
+struct shape3 {
+    unsigned v[3];
+    shape3(unsigned x = 0, unsigned y = 0, unsigned z = 0) : v{x, y, z} {}
+    unsigned& operator[](size_t i) { return v[i]; }
+    const unsigned& operator[](size_t i) const { return v[i]; }
+    size_t size() const { return (size_t)v[0] * v[1] * v[2]; }
+};
+inline std::ostream& operator<<(std::ostream& o, const vector3& a) { return o << a[0] << " " << a[1] << " " << a[2]; }
+inline std::ostream& operator<<(std::ostream& o, const shape3& a) { return o << a[0] << " " << a[1] << " " << a[2]; }
+}  // namespace unet_types
+#endif
+
+struct unet_plan;
+
+struct UNet3dImpl : torch::nn::Module
+{
+public:
+    int in_count = 1;
+    int out_count = 1;
+    std::string architecture,preproc,postproc,orientation,fov_strategy,error_msg;
+public:
+    std::shared_ptr<torch::optim::SGD> optimizer;
+
+    std::vector<float> testing_errors,training_errors;
+    std::vector<unsigned int> single_component_label;
+    mutable std::mutex error_mutex;
+    auto get_training_errors(void) const
+    {
+        std::scoped_lock<std::mutex> lock(error_mutex);
+        return std::vector<float>(training_errors);
+    }
+    auto get_testing_errors(void) const
+    {
+        std::scoped_lock<std::mutex> lock(error_mutex);
+        return std::vector<float>(testing_errors);
+    }
+
+public:
+    unet_types::vector3 voxel_size = {1.0f,1.0f,1.0f};
+    unet_types::shape3 dim = {192,224,192};
+    // kept for source compatibility (the reference exposes them); the layers live in the lowered HIP plan
+    std::deque<torch::nn::Sequential> encoding,decoding,decoding_tail;
+    std::vector<torch::nn::Sequential> output;
+    int create_layer(torch::nn::Sequential& layers,const std::string& def, int in_c);
+public:
+    std::string get_info(void) const;
+public:
+    UNet3dImpl(void){}
+    UNet3dImpl(int32_t in_count_,int32_t out_count_,std::string);
+    ~UNet3dImpl(void);
+    void copy_from(const UNet3dImpl& r);
+    void add_gradient_from(const UNet3dImpl& r);
+    void create_optimizer(float learning_rate);
+public:
+    std::vector<torch::Tensor> forward(torch::Tensor inputTensor);
+
+    void set_requires_grad(bool req)
+    {
+        for (auto& p : parameters())
+            p.set_requires_grad(req);
+    }
+    virtual void train(bool on = true) override
+    {
+        set_requires_grad(on);
+        torch::nn::Module::train(on);
+    }
+    void print_layers(void);
+    torch::Device device(void) const
+    {
+        return parameters().size() && parameters()[0].defined() ? parameters()[0].device() : torch::kCPU;
+    }
+    void prepare_for_inference(const torch::Device& device);
+
+public: // ---- engine side (not in the reference) ----
+    int engine_dtype = 1;                  // UNET_DTYPE_BF16 (0 = fp32 parity configuration)
+    torch::Tensor flat_params, flat_grads; // fp32, parameters() order; the registered parameters are views
+    void to_device(const torch::Device& device);   // what to(device) means for the flat storage
+    // fused micro-step pieces (train.cpp:634-706 and 759-766 without autograd), optional for callers
+    torch::Tensor loss_and_backward(torch::Tensor input, torch::Tensor target_int64, bool ce, bool dice, bool mse, int collapse_before = 0);
+    void sgd_step(float lr, float grad_scale, float clip_norm = 12.0f);
+private:
+    friend struct UNetForwardFn;
+    std::vector<torch::Tensor> params_, buffers_;
+    std::map<std::array<int64_t,3>, unet_plan*> plans_;
+    std::map<std::pair<unet_plan*, size_t>, torch::Tensor> workspaces_;   // (plan, thread) -> workspace
+    std::mutex plans_mutex_;
+    torch::Tensor trigger_, momentum_, scratch_;
+    unet_plan* plan_for(int64_t d,int64_t h,int64_t w);
+    torch::Tensor workspace_for(unet_plan* plan);
+    void bind_views(void);
+    void ensure_flat(void);
+    void rebind_grads(void);
+    std::vector<torch::Tensor> run_forward(unet_plan* plan, torch::Tensor ws, torch::Tensor x, int mode);
+    void run_backward(unet_plan* plan, torch::Tensor ws, const std::vector<torch::Tensor>& grad_outs);
+};
+TORCH_MODULE_IMPL(UNet3d, UNet3dImpl);
+
+
+#endif// UNET_HPP

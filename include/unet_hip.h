@@ -55,6 +55,8 @@ void unet_plan_destroy(unet_plan* plan);
 /* parameters() order (unet.cpp:130,160-164).  dims has room for 5 entries. */
 int unet_plan_param_count(const unet_plan* plan, int* n);
 int unet_plan_param_shape(const unet_plan* plan, int i, int64_t dims[5], int* ndim);
+/* named_parameters() key of parameter i, e.g. "encode0.3.weight" (module registration names of unet.cpp:130,160-164) */
+int unet_plan_param_name(const unet_plan* plan, int i, char* name, size_t name_len);
 /* 1 if weight decay applies to parameter i (unet.cpp:254: dim > 1 and no "bias" in the name) */
 int unet_plan_param_decay(const unet_plan* plan, int i, int* decay);
 /* fan_in of parameter i's owning conv (0 for norm affine): default-init bound 1/sqrt(fan_in) */

@@ -1,0 +1,115 @@
+// GPU parity test of the C++ drop-in (include/unet.hpp + unet_host.cpp) against a libtorch CPU network assembled
+// with the same torch::nn modules, in the same order, as the reference's unet.cpp:24-193 builds for this DSL string.
+// Exit code 0 and "OK" on success.  Usage: test_unet_hpp [fp32|bf16]
+#include "unet.hpp"
+#include <iostream>
+
+static double rel(const torch::Tensor& a, const torch::Tensor& b) {
+    auto A = a.to(torch::kCPU).to(torch::kFloat64), B = b.to(torch::kCPU).to(torch::kFloat64);
+    return ((A - B).abs().max() / B.abs().max().clamp_min(1e-30)).item<double>();
+}
+#define REQUIRE(cond, msg) do { if (!(cond)) { std::cerr << "FAILED: " << msg << std::endl; return 1; } } while (0)
+
+// reference-order network for:  conv8,ks3,stride1+norm,leaky_relu \n conv16,ks3,stride2+norm,leaky_relu+conv_trans8,ks2,stride2 \n
+//                               conv8,ks3,stride1+norm,leaky_relu+conv3,ks1,stride1
+struct RefNet : torch::nn::Module {
+    torch::nn::Sequential e0, e1, d0, o0;
+    RefNet() {
+        namespace nn = torch::nn;
+        e0 = nn::Sequential(nn::Conv3d(nn::Conv3dOptions(1, 8, 3).stride(1).padding(1)), nn::InstanceNorm3d(nn::InstanceNorm3dOptions(8).affine(true)),
+                            nn::LeakyReLU(nn::LeakyReLUOptions().negative_slope(0.01)));
+        e1 = nn::Sequential(nn::Conv3d(nn::Conv3dOptions(8, 16, 3).stride(2).padding(1)), nn::InstanceNorm3d(nn::InstanceNorm3dOptions(16).affine(true)),
+                            nn::LeakyReLU(nn::LeakyReLUOptions().negative_slope(0.01)), nn::ConvTranspose3d(nn::ConvTranspose3dOptions(16, 8, 2).stride(2)));
+        d0 = nn::Sequential(nn::Conv3d(nn::Conv3dOptions(16, 8, 3).stride(1).padding(1)), nn::InstanceNorm3d(nn::InstanceNorm3dOptions(8).affine(true)),
+                            nn::LeakyReLU(nn::LeakyReLUOptions().negative_slope(0.01)));
+        o0 = nn::Sequential(nn::Conv3d(nn::Conv3dOptions(8, 3, 1).stride(1).padding(0)));
+        register_module("encode0", e0); register_module("encode1", e1); register_module("decode0", d0); register_module("output0", o0);
+    }
+    torch::Tensor forward(torch::Tensor x) {
+        auto s = e0->forward(x);
+        auto y = e1->forward(s);
+        y = d0->forward(torch::cat({s, y}, 1));
+        return o0->forward(y);
+    }
+};
+
+int main(int argc, char** argv) {
+    bool bf16 = argc > 1 && std::string(argv[1]) == "bf16";
+    double tol = bf16 ? 4e-2 : 1e-4, gtol = bf16 ? 8e-2 : 2e-4;
+    if (!torch::cuda::is_available()) { std::cerr << "needs a GPU" << std::endl; return 2; }
+    torch::manual_seed(0);
+    const std::string arch = "conv8,ks3,stride1+norm,leaky_relu\nconv16,ks3,stride2+norm,leaky_relu+conv_trans8,ks2,stride2\n"
+                             "conv8,ks3,stride1+norm,leaky_relu+conv3,ks1,stride1";
+    // DSL errors surface as std::runtime_error with the reference's messages (unet.cpp:66)
+    try { UNet3d bad(1, 3, std::string("conv8,ks5\nconv8\nconv8")); REQUIRE(false, "bad DSL accepted"); }
+    catch (const std::runtime_error& e) { REQUIRE(std::string(e.what()).find("conv supports only") != std::string::npos, e.what()); }
+
+    auto ref = std::make_shared<RefNet>();
+    UNet3d model(1, 3, arch);
+    model->engine_dtype = bf16 ? 1 : 0;
+    {   // same parameters() order and named_parameters() keys as the reference's module tree
+        auto rp = ref->named_parameters(), mp = model->named_parameters();
+        REQUIRE(rp.size() == mp.size(), "parameter count");
+        torch::NoGradGuard ng;
+        for (size_t i = 0; i < rp.size(); ++i) {
+            REQUIRE(rp[i].key() == mp[i].key(), "parameter name " + rp[i].key() + " vs " + mp[i].key());
+            REQUIRE(rp[i].value().sizes() == mp[i].value().sizes(), "parameter shape " + rp[i].key());
+            mp[i].value().copy_(rp[i].value());
+        }
+    }
+    torch::Device dev(torch::kCUDA, 0);
+    model->to(dev);                       // torch::nn::Module::to, as train.cpp:940 does
+    model->train();
+    model->create_optimizer(0.01f);
+    REQUIRE(model->device() == dev, "device()");
+
+    auto x = torch::rand({1, 1, 12, 16, 20});
+    auto w = torch::randn({1, 3, 12, 16, 20});
+    ref->train();
+    auto yr = ref->forward(x);
+    (yr * w).sum().backward();
+    auto outs = model->forward(x.to(dev));
+    REQUIRE(outs.size() == 1 && outs[0].sizes() == yr.sizes(), "output shape");
+    REQUIRE(rel(outs[0], yr) < tol, "train-mode logits: " + std::to_string(rel(outs[0], yr)));
+    (outs[0] * w.to(dev)).sum().backward();
+    double gmax = 0;
+    for (auto& p : ref->parameters()) gmax = std::max(gmax, p.grad().abs().max().item<double>());
+    auto rp = ref->parameters(), mp = model->parameters();
+    for (size_t i = 0; i < rp.size(); ++i) {
+        REQUIRE(mp[i].grad().defined(), "grad defined");
+        double e = (mp[i].grad().to(torch::kCPU) - rp[i].grad()).abs().max().item<double>() / gmax;
+        REQUIRE(e < gtol, "grad " + std::to_string(i) + ": " + std::to_string(e));
+    }
+    // step epilogue exactly as train.cpp:759-766 does it, with the torch optimizer both sides
+    auto ropt = torch::optim::SGD(ref->parameters(), torch::optim::SGDOptions(0.01).momentum(0.99).nesterov(true));
+    for (auto& p : model->parameters()) p.grad().div_(1);
+    torch::nn::utils::clip_grad_norm_(model->parameters(), 12.0);
+    torch::nn::utils::clip_grad_norm_(ref->parameters(), 12.0);
+    model->optimizer->step(); model->optimizer->zero_grad();
+    // second micro-step after zero_grad (grads were set to None): accumulation path
+    auto outs2 = model->forward(x.to(dev));
+    (outs2[0] * w.to(dev)).sum().backward();
+    REQUIRE(model->parameters()[0].grad().defined() && model->parameters()[0].grad().abs().max().item<float>() > 0, "grad after zero_grad");
+    // eval: prepare_for_inference + no-grad forward (evaluate.cpp:211-246)
+    model->prepare_for_inference(dev);
+    {
+        torch::NoGradGuard ng;
+        auto ye = model->forward(x.to(dev))[0];
+        REQUIRE(ye.sizes() == yr.sizes() && torch::isfinite(ye).all().item<bool>(), "eval forward");
+    }
+    // copy_from / add_gradient_from between replicas (train.cpp:575,757)
+    UNet3d replica(1, 3, arch);
+    replica->engine_dtype = model->engine_dtype;
+    replica->to(dev);
+    replica->copy_from(*model);
+    REQUIRE(rel(replica->parameters()[0], model->parameters()[0]) == 0.0, "copy_from");
+    replica->train();
+    auto outs3 = replica->forward(x.to(dev));
+    (outs3[0] * w.to(dev)).sum().backward();
+    auto before = model->flat_grads.clone();
+    model->add_gradient_from(*replica);
+    REQUIRE(rel(model->flat_grads, before + replica->flat_grads) < 1e-6, "add_gradient_from");
+    std::cout << model->get_info();
+    std::cout << "OK " << (bf16 ? "bf16" : "fp32") << " logits rel " << rel(outs[0], yr) << std::endl;
+    return 0;
+}

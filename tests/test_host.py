@@ -35,6 +35,7 @@ def test_plan_matches_reference_parameter_order_default_arch():
     # weight decay mask, unet.cpp:254
     names = [n for n, _ in ref.named_parameters()]
     assert p.param_decay == [not ("bias" in n or q.dim() <= 1) for n, q in ref.named_parameters()], names
+    assert p.param_names == names     # named_parameters() keys: "encode0.0.weight", ..., "output0.0.bias"
     assert p.output_shapes == [(1, 6, 128 >> l, 128 >> l, 128 >> l) for l in range(5)]
     # BASELINE.md §4 algorithmic work
     assert abs(p.flops_fwd - 245.165e9) < 0.01e9 and abs(p.flops_bwd - 488.518e9) < 0.01e9

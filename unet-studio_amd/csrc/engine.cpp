@@ -552,6 +552,11 @@ int unet_plan_param_shape(const unet_plan* p, int i, int64_t dims[5], int* ndim)
     for (size_t k = 0; k < s.size(); ++k) dims[k] = s[k];
     return 0;
 }
+int unet_plan_param_name(const unet_plan* p, int i, char* name, size_t name_len) {
+    if (i < 0 || i >= (int)p->g.params.size()) return fail("parameter index out of range");
+    if (name && name_len) { std::strncpy(name, p->g.params[i].name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    return 0;
+}
 int unet_plan_param_decay(const unet_plan* p, int i, int* decay) {
     if (i < 0 || i >= (int)p->g.params.size()) return fail("parameter index out of range");
     *decay = p->g.params[i].decay;

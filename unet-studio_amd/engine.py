@@ -38,6 +38,7 @@ _sig("unet_plan_create", _i, C.c_char_p, _i, _i, _i, _i, _i, _i, _i, _i, C.POINT
 _sig("unet_plan_destroy", None, _vp)
 _sig("unet_plan_param_count", _i, _vp, C.POINTER(_i))
 _sig("unet_plan_param_shape", _i, _vp, _i, C.POINTER(C.c_int64), C.POINTER(_i))
+_sig("unet_plan_param_name", _i, _vp, _i, C.c_char_p, _sz)
 _sig("unet_plan_param_decay", _i, _vp, _i, C.POINTER(_i))
 _sig("unet_plan_param_fan_in", _i, _vp, _i, C.POINTER(C.c_int64), C.POINTER(_i))
 _sig("unet_plan_buffer_count", _i, _vp, C.POINTER(_i))
@@ -66,7 +67,7 @@ _sig("unet_op_unpack_ncdhw", _i, _i, _vp, _vp, _i, C.c_int64, _vp)
 # every symbol include/unet_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "unet_last_error", "unet_init", "unet_device_info", "unet_plan_create", "unet_plan_destroy", "unet_plan_param_count",
-    "unet_plan_param_shape", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
+    "unet_plan_param_shape", "unet_plan_param_name", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
     "unet_plan_buffer_shape", "unet_plan_output_count", "unet_plan_output_shape", "unet_plan_workspace_bytes",
     "unet_plan_flops", "unet_plan_describe", "unet_forward", "unet_backward", "unet_loss_scratch_bytes", "unet_loss",
     "unet_sgd_step", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
@@ -101,11 +102,14 @@ class Plan:
         self.arch, self.in_c, self.out_c, self.size, self.dtype, self.device = arch, in_c, out_c, (D, H, W), dtype, device
         n = C.c_int()
         check(lib.unet_plan_param_count(self.handle, C.byref(n)))
-        self.param_shapes, self.param_decay, self.param_fan_in, self.param_is_norm_weight = [], [], [], []
+        self.param_shapes, self.param_decay, self.param_fan_in, self.param_is_norm_weight, self.param_names = [], [], [], [], []
         dims, nd, dec, fan, isn = (C.c_int64 * 5)(), C.c_int(), C.c_int(), C.c_int64(), C.c_int()
         for i in range(n.value):
             check(lib.unet_plan_param_shape(self.handle, i, dims, C.byref(nd)))
             self.param_shapes.append(tuple(dims[k] for k in range(nd.value)))
+            nm = C.create_string_buffer(128)
+            check(lib.unet_plan_param_name(self.handle, i, nm, 128))
+            self.param_names.append(nm.value.decode())
             check(lib.unet_plan_param_decay(self.handle, i, C.byref(dec)))
             self.param_decay.append(bool(dec.value))
             check(lib.unet_plan_param_fan_in(self.handle, i, C.byref(fan), C.byref(isn)))
