@@ -62,7 +62,7 @@ UNet3dImpl::UNet3dImpl(int32_t in_count_, int32_t out_count_, std::string archit
     for (int i = 0; i < n; ++i) {
         int64_t e = 1;
         for (auto v : shapes[i]) e *= v;
-        auto view = flat_params.narrow(0, off, e).view(shapes[i]);
+        auto view = torch::from_blob(flat_params.data_ptr<float>() + off, shapes[i], torch::TensorOptions().dtype(torch::kFloat32));
         if (fan[i] > 0) view.uniform_(-1.0 / std::sqrt((double)fan[i]), 1.0 / std::sqrt((double)fan[i]));
         else view.fill_(isnw[i] ? 1.0f : 0.0f);
         off += e;
@@ -96,12 +96,14 @@ UNet3dImpl::~UNet3dImpl(void)
 // parameters and their .grad are views into the two flat buffers (one all-reduce / one SGD launch over everything)
 void UNet3dImpl::bind_views(void)
 {
+    // aliases made with from_blob, not autograd views: optimizer->zero_grad() calls grad.detach_(), which views refuse
     int64_t off = 0;
+    auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(flat_params.device());
     for (auto& p : params_) {
         int64_t e = p.numel();
         torch::NoGradGuard ng;
-        p.set_data(flat_params.narrow(0, off, e).view(p.sizes()));
-        p.mutable_grad() = flat_grads.narrow(0, off, e).view(p.sizes());
+        p.set_data(torch::from_blob(flat_params.data_ptr<float>() + off, p.sizes(), opts));
+        p.mutable_grad() = torch::from_blob(flat_grads.data_ptr<float>() + off, p.sizes(), opts);
         off += e;
     }
 }
@@ -154,11 +156,15 @@ void UNet3dImpl::rebind_grads(void)
 {
     torch::NoGradGuard ng;
     int64_t off = 0;
+    auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(flat_grads.device());
     for (auto& p : params_) {
         int64_t e = p.numel();
-        auto view = flat_grads.narrow(0, off, e).view(p.sizes());
-        if (!p.grad().defined()) { view.zero_(); p.mutable_grad() = view; }
-        else if (p.grad().data_ptr() != view.data_ptr()) { view.copy_(p.grad()); p.mutable_grad() = view; }
+        float* slot = flat_grads.data_ptr<float>() + off;
+        if (!p.grad().defined() || p.grad().data_ptr() != (void*)slot) {
+            auto alias = torch::from_blob(slot, p.sizes(), opts);
+            if (p.grad().defined()) alias.copy_(p.grad()); else alias.zero_();
+            p.mutable_grad() = alias;
+        }
         off += e;
     }
 }
