@@ -693,7 +693,7 @@ int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes)
         b += align_up(blocks * cout * 2 * 4);
     }
     if ((int64_t)cin * cout <= 1024) {   // small-weight wgrad slabs: <= 1024 row blocks x <= 1024 weights, + bias partials
-        size_t w = ((size_t)1024 * 1024 + (size_t)256 * cout) * 4 + 256;
+        size_t w = ((size_t)1024 * 1024 + (size_t)1024 * cout) * 4 + 1024;
         if (w > b) b = w;
     }
     if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {

@@ -147,6 +147,8 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
 bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s);
+// vectorised per-block column sums partial[blk][C] of a bf16 [S][C] tensor; returns #blocks (0: not applicable)
+int launch_colsum_partial8(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s);
 size_t bias_grad_scratch_bytes(int C, int64_t S);
 void launch_bias_grad(int dtype, const void* dy, int C, int64_t S, float* db, void* scratch, hipStream_t s);
 // dgrad of a 3x3x3 conv, stride 1 or 2 (g = forward geometry)

@@ -414,8 +414,15 @@ static void launch_wgrad_common(int dtype, const ConvGeom& g, const SrcDesc* src
     }
 }
 // db[c] += sum_v dy[v][c]   (scratch: bias_grad_scratch_bytes, or nullptr for a single-block-per-channel pass)
-size_t bias_grad_scratch_bytes(int C, int64_t S) { return (size_t)bias_split(S) * C * 4 + 256; }
+size_t bias_grad_scratch_bytes(int C, int64_t S) {
+    size_t a = (size_t)bias_split(S) * C * 4, b = (size_t)stats_blocks(S) * C * 4;
+    return (a > b ? a : b) + 256;
+}
 void launch_bias_grad(int dtype, const void* dy, int C, int64_t S, float* db, void* scratch, hipStream_t s) {
+    if (scratch) {   // coalesced 16-B loads when the channel count allows
+        int nb = launch_colsum_partial8(dtype, dy, C, S, (float*)scratch, s);
+        if (nb > 0) { slab_reduce((const float*)scratch, nb, C, db, s); return; }
+    }
     int bs = scratch ? bias_split(S) : 1;
     float* bslab = bs > 1 ? (float*)scratch : nullptr;
     UNET_DISPATCH(dtype, (k_bias_grad<T><<<dim3(C, bs), 256, 0, s>>>((const T*)dy, C, S, db, bslab)));
@@ -583,7 +590,7 @@ bool wgrad_small_supported(const ConvGeom& g) {
 size_t wgrad_small_scratch_bytes(const ConvGeom& g) {
     int k3 = g.ks * g.ks * g.ks;
     int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
-    return ((size_t)wgrad_small_blocks(g) * k3 * g.Cin * g.Cout + (size_t)bias_split(So) * g.Cout) * 4 + 256;
+    return (size_t)wgrad_small_blocks(g) * k3 * g.Cin * g.Cout * 4 + bias_grad_scratch_bytes(g.Cout, So) + 256;
 }
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
                              void* scratch, hipStream_t s) {

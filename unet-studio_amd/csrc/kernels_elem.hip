@@ -169,6 +169,39 @@ __global__ void __launch_bounds__(256) k_norm_bwd_apply8(uint4* __restrict__ g8,
         g8[v * G8 + grp] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
+// per-block column sums of a bf16 [S][C] tensor (bias gradient), same thread geometry as k_norm_bwd_stats8
+__global__ void __launch_bounds__(256) k_colsum8(const uint4* __restrict__ x8, int C, int64_t S, int64_t VPB, float* __restrict__ partial) {
+    __shared__ float red[256][9];
+    const int G8 = C / 8, NV = 256 / G8, grp = threadIdx.x % G8, lane = threadIdx.x / G8;
+    const int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
+    float s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = 0.f;
+    for (int64_t v = v0 + lane; v < v1; v += NV) {
+        float f[8];
+        unpack8(x8[v * G8 + grp], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s1[e];
+    __syncthreads();
+    if (threadIdx.x < G8 * 8) {
+        const int gg = threadIdx.x / 8, e = threadIdx.x % 8;
+        float a = 0.f;
+        for (int l = 0; l < NV; ++l) a += red[l * G8 + gg][e];
+        partial[(int64_t)blockIdx.x * C + gg * 8 + e] = a;
+    }
+}
+static inline bool vec8_ok(int dtype, int C);
+// partial[blk][C]; returns the number of blocks, 0 when the vectorised form does not apply
+int launch_colsum_partial8(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s) {
+    if (!vec8_ok(dtype, C)) return 0;
+    int nb = stats_blocks(S);
+    k_colsum8<<<nb, 256, 0, s>>>((const uint4*)x, C, S, stats_vpb(S), partial);
+    return nb;
+}
+
 static inline bool vec8_ok(int dtype, int C) {
     if (dtype != 1 || C % 8) return false;
     int g8 = C / 8;
