@@ -92,75 +92,54 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
     const int actb = a.bsrc.act;
     const bool do_bias = a.bias_slab != nullptr && ciB == 0;
 
-    // Software pipeline over this block's tiles: the global loads of tile k+1 are issued into registers before the MFMAs
-    // of tile k and written to LDS after them (same scheme as k_mfma_conv_p).
-    constexpr int UNITS_A = NVA * GA, ITERS_A = (UNITS_A + 255) / 256;
-    constexpr int UNITS_B = NVB * GB, ITERS_B = (UNITS_B + 255) / 256;
-    static_assert(ITERS_A <= 32 && ITERS_B <= 32, "in-bounds masks are 32-bit words");
-    uint4 RA[ITERS_A], RB[ITERS_B];
-    unsigned inA = 0, inB = 0;
-    auto prefetch = [&](int tile) {
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ox0 = (tile % a.tiles_x) * BX, oy0 = ((tile / a.tiles_x) % a.tiles_y) * BY, oz0 = (tile / (a.tiles_x * a.tiles_y)) * BZ;
         const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD, iz0 = oz0 * S - PAD;
-        inA = 0; inB = 0;
-#pragma unroll
-        for (int itr = 0; itr < ITERS_A; ++itr) {
-            const int u = tid + itr * 256, hv = u / GA;
-            const int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
-            const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
-            RA[itr] = make_uint4(0u, 0u, 0u, 0u);
-            if (u < UNITS_A && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
-                size_t vox = ((size_t)gz * g.H + gy) * g.W + gx;
-                RA[itr] = *(const uint4*)(abase + vox * (size_t)sd.C * 2);
-                inA |= 1u << itr;
-            }
-        }
-#pragma unroll
-        for (int itr = 0; itr < ITERS_B; ++itr) {
-            const int u = tid + itr * 256, tv = u / GB;
-            const int tz = tv / (BY * BX), tr = tv % (BY * BX), ty = tr / BX, tx = tr % BX;
-            const int gz = oz0 + tz, gy = oy0 + ty, gx = ox0 + tx;
-            RB[itr] = make_uint4(0u, 0u, 0u, 0u);
-            if (u < UNITS_B && gz < g.Do && gy < g.Ho && gx < g.Wo) {
-                size_t vox = ((size_t)gz * g.Ho + gy) * g.Wo + gx;
-                RB[itr] = *(const uint4*)(bbase + vox * (size_t)g.Cout * 2);
-                inB |= 1u << itr;
-            }
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int itr = 0; itr < ITERS_A; ++itr) {
-            const int u = tid + itr * 256;
-            if (u < UNITS_A) {
-                uint4 v = RA[itr];
-                if ((inA >> itr) & 1u) v = transform8(v, xf, sc, sh, act);
-                *(uint4*)(smem + (ua >> 1) * PLANE_A + (u / GA) * 32 + (ua & 1) * 16) = v;
-            }
-        }
-#pragma unroll
-        for (int itr = 0; itr < ITERS_B; ++itr) {
-            const int u = tid + itr * 256;
-            if (u < UNITS_B) {
-                uint4 v = RB[itr];
-                if ((inB >> itr) & 1u) {
-                    if (do_bias) {   // sums of the RAW tile-side values (zeros outside the volume add nothing)
-                        bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
-                        bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
-                    }
-                    v = transform8(v, xfb, scb, shb, actb);
-                }
-                *(uint4*)(smem + B_OFF + (ub >> 1) * PLANE_B + (u / GB) * 32 + (ub & 1) * 16) = v;
-            }
-        }
-    };
-
-    if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();                  // every wave is done reading the previous tile
-        commit();
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);   // in flight during the MFMAs below
+        // ---- stage A: halo tile ----
+        {
+            constexpr int UNITS = NVA * GA, ITERS = (UNITS + 255) / 256;
+#pragma unroll 4
+            for (int itr = 0; itr < ITERS; ++itr) {
+                int u = tid + itr * 256;
+                if (u < UNITS) {
+                    int hv = u / GA;
+                    int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
+                    int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+                        size_t vox = ((size_t)gz * g.H + gy) * g.W + gx;
+                        v = transform8(*(const uint4*)(abase + vox * (size_t)sd.C * 2), xf, sc, sh, act);
+                    }
+                    *(uint4*)(smem + (ua >> 1) * PLANE_A + hv * 32 + (ua & 1) * 16) = v;
+                }
+            }
+        }
+        // ---- stage B: tile (+ bias partial sums of the raw values) ----
+        {
+            constexpr int UNITS = NVB * GB, ITERS = (UNITS + 255) / 256;
+#pragma unroll 4
+            for (int itr = 0; itr < ITERS; ++itr) {
+                int u = tid + itr * 256;
+                if (u < UNITS) {
+                    int tv = u / GB;
+                    int tz = tv / (BY * BX), tr = tv % (BY * BX), ty = tr / BX, tx = tr % BX;
+                    int gz = oz0 + tz, gy = oy0 + ty, gx = ox0 + tx;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (gz < g.Do && gy < g.Ho && gx < g.Wo) {
+                        size_t vox = ((size_t)gz * g.Ho + gy) * g.Wo + gx;
+                        v = *(const uint4*)(bbase + vox * (size_t)g.Cout * 2);
+                        if (do_bias) {
+                            bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+                            bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+                        }
+                        v = transform8(v, xfb, scb, shb, actb);
+                    }
+                    *(uint4*)(smem + B_OFF + (ub >> 1) * PLANE_B + tv * 32 + (ub & 1) * 16) = v;
+                }
+            }
+        }
+        __syncthreads();
         // ---- MFMA: this wave's K-steps ----
         const char* pa = smem + it_ * PLANE_A + p4 * 8;
         const char* pb = smem + B_OFF + jt * PLANE_B + p4 * 8;
