@@ -46,9 +46,11 @@ def dominant_kernel(U, size, dtype_name, iters=10):
     sc = torch.empty(nb.value, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
 
-    def run():
-        E.check(E.lib.unet_op_conv3d_fwd(edt, U.IMPL_AUTO, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), cin, cout,
-                                         D, H, W, 3, 1, sc.data_ptr(), st))
+    stats = torch.empty((cout, 2), device=dev)
+
+    def run():   # exactly the launch the network makes for decode0.0: no read-side transform, norm-statistics epilogue
+        E.check(E.lib.unet_op_conv3d_fwd_fused(edt, U.IMPL_AUTO, x.data_ptr(), None, None, 0, w.data_ptr(), b.data_ptr(), y.data_ptr(),
+                                               stats.data_ptr(), cin, cout, D, H, W, 3, 1, sc.data_ptr(), st))
     run(); run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -60,6 +62,16 @@ def dominant_kernel(U, size, dtype_name, iters=10):
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * cin * cout * 27 * D * H * W
     return flops, sec
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950, + WRITE_SIZE), recorded by profiles/collect_traffic.sh into profiles/dominant_kernel_traffic.json."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(size, budget_steps=1):
@@ -166,7 +178,7 @@ def main():
                        "flops_per_step_per_sample": step_flops, "params": int(model.flat_params.numel())},
             "step_mfma_frac": (step_flops * world * a.steps / dt) / (peak * world),
             "roofline": {"bound": "mfma", "achieved": kflops / ksec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": kflops / ksec / peak, "traffic": None,
+                         "frac": kflops / ksec / peak, "traffic": measured_traffic(),
                          "kernel": "conv3d fwd 32->16 3x3x3 @%d^3 (decode0.0, 23.7%% of forward FLOPs)" % n,
                          "avg_launch_ms": ksec * 1e3},
             "last_loss": loss,
