@@ -298,18 +298,31 @@ static void run_pack(const float* w, void* out, int Ci, int Co, int CK, int T, i
 // latency hides under the matrix work even at 2 blocks per CU (measured: the one-shot kernel spent ~6 % of
 // a block's lifetime in MFMAs, the rest waiting for the halo tile).
 // ------------------------------------------------------------------------------------------------
-template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
-__global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC, int NW>
+__global__ void __launch_bounds__(NW * 64) k_mfma_conv_p(MfmaConvArgs a) {
+    constexpr int NTHR = NW * 64;   // 8 waves on the larger tiles: half the staging registers per thread, 4 waves per SIMD at 2 blocks/CU
     constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD, NVOX = HZ * HY * HX;
     constexpr int G = CK / 8;
-    constexpr int VS = CK == 32 ? 96 : 32;
+    // 3x3x3 stride-1 tiles with 64-B voxels: unpadded 64-B voxels, rows padded to a multiple of 4 voxels (row starts on a
+    // 256-B bank row) and the 16-B group index XOR-ed with bit 2 of the voxel's x (swz): conflict-free ds_read_b128 for
+    // 16 consecutive x at any tap shift (checked exhaustively offline), 46 KB instead of 62 KB per tile -> 3 blocks/CU.
+    constexpr bool SWZ = CK == 32 && S == 1 && KD == 3;
+    constexpr int VS = SWZ ? 64 : (CK == 32 ? 96 : 32);
+    constexpr int HXP = SWZ ? (HX + 3) / 4 * 4 : HX;   // row pitch in voxels
     constexpr int TXM = BX < 16 ? BX : 16;
     constexpr int TYM = 16 / TXM;
-    constexpr int MT = BZ * BY * BX / 16, MTW = MT / 4;
+    constexpr int MT = BZ * BY * BX / 16, MTW = MT / NW;
     constexpr int T = KD * KD * KD;
     constexpr int KSTEPS = CK == 32 ? T : (T + 1) / 2;
-    constexpr int UNITS = NVOX * G, ITERS = (UNITS + 255) / 256;
-    static_assert(MT % 4 == 0 && MTW >= 1, "tile must give every wave at least one m-tile");
+    constexpr int UNITS = NVOX * G, ITERS = (UNITS + NTHR - 1) / NTHR;
+    constexpr int NKX = SWZ ? 3 : 1;
+    // The chunk's filter fragments live in LDS behind the tile when they fit (<= 32 KB): in the ISA of the first version
+    // every tap waited on a global (L2) load issued one tap earlier -- ~27 exposed L2 latencies per tile, the whole
+    // difference between ~6 % and the MFMA-issue-limited rate.  With Cin <= CK they are loaded once per block.
+    constexpr bool WLDS = KSTEPS * NT <= 32;
+    constexpr int TILE_B = HZ * HY * HXP * VS;
+    constexpr int WPIECES = KSTEPS * NT * 64, WITERS = WLDS ? (WPIECES + NTHR - 1) / NTHR : 1;
+    static_assert(MT % NW == 0 && MTW >= 1, "tile must give every wave at least one m-tile");
     static_assert(ITERS <= 32, "in-bounds mask is one 32-bit word");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -322,13 +335,21 @@ __global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
     const int nchunk = g.Cin / CK;
     const bf16x8* wp = (const bf16x8*)a.w;
 
-    int mz[MTW], my[MTW], mx[MTW], mbase[MTW];
+    int mz[MTW], my[MTW], mx[MTW], mbase[MTW][NKX];
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         int mt = wave * MTW + i;
         constexpr int RG = BY / TYM;
         mz[i] = mt / RG; my[i] = (mt % RG) * TYM + (j / TXM); mx[i] = j % TXM;
-        mbase[i] = ((mz[i] * S * HY + my[i] * S) * HX + mx[i] * S) * VS + (CK == 32 ? gq : (gq & 1)) * 16;
+        if (SWZ) {
+#pragma unroll
+            for (int kx = 0; kx < NKX; ++kx) {
+                const int hx = mx[i] + kx;
+                mbase[i][kx] = ((mz[i] * HY + my[i]) * HXP + hx) * 64 + ((gq ^ (((hx >> 2) & 1) << 1)) << 4);
+            }
+        } else {
+            mbase[i][0] = ((mz[i] * S * HY + my[i] * S) * HX + mx[i] * S) * VS + (CK == 32 ? gq : (gq & 1)) * 16;
+        }
     }
     f32x4 acc[MTW][NT];
 #pragma unroll
@@ -340,11 +361,21 @@ __global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
     const int my_tiles = nblk > (int)blockIdx.x ? (nblk - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nst = my_tiles * nchunk;
 
-    uint4 R[ITERS];
+    uint4 R[ITERS], RW[WITERS];
     unsigned inb = 0;
     // issue the global loads of stage st into R (no waiting)
     auto prefetch = [&](int st) {
         const int k = st / nchunk, q = st - k * nchunk;
+        if (WLDS && (nchunk > 1 || st == 0)) {
+#pragma unroll
+            for (int it = 0; it < WITERS; ++it) {
+                const int pc = tid + it * NTHR;         // piece = (ks, n, lane)
+                if (pc < WPIECES) {
+                    const int l = pc & 63, kn = pc >> 6, n = kn % NT, ks = kn / NT;
+                    RW[it] = *(const uint4*)(wp + (((size_t)q * KSTEPS + ks) * NTT + nt0 + n) * 64 + l);
+                }
+            }
+        }
         const int bid = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, nblk);
         const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
         const int iz0 = z0 * S - PAD, iy0 = y0 * S - PAD, ix0 = x0 * S - PAD;
@@ -355,7 +386,7 @@ __global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
         inb = 0;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int u = tid + it * 256;
+            const int u = tid + it * NTHR;
             const int hv = u / G;
             const int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
             const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
@@ -370,6 +401,13 @@ __global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
     // transform (if the source carries one) and write R to the LDS tile
     auto commit = [&](int st) {
         const int k = st / nchunk, q = st - k * nchunk;
+        if (WLDS && (nchunk > 1 || st == 0)) {
+#pragma unroll
+            for (int it = 0; it < WITERS; ++it) {
+                const int pc = tid + it * NTHR;
+                if (pc < WPIECES) *(uint4*)(smem + TILE_B + pc * 16) = RW[it];
+            }
+        }
         const int c = q * CK + lg * 8;
         const int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
         const SrcDesc& sd = a.src[s];
@@ -383,57 +421,64 @@ __global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
-            const int u = tid + it * 256;
+            const int u = tid + it * NTHR;
             if (u < UNITS) {
                 uint4 v = R[it];
                 if ((xf || act) && ((inb >> it) & 1u)) v = transform8(v, xf, sc, sh, act);
-                *(uint4*)(smem + (u / G) * VS + lg * 16) = v;
+                if (SWZ) {
+                    const int hv = u / G, row = hv / HX, hx = hv % HX;
+                    *(uint4*)(smem + (row * HXP + hx) * 64 + ((lg ^ (((hx >> 2) & 1) << 1)) << 4)) = v;
+                } else {
+                    *(uint4*)(smem + (u / G) * VS + lg * 16) = v;
+                }
             }
         }
     };
-
-    // Filter fragments of a whole chunk kept in registers when they fit (<= 112 VGPRs): their L2 latency is paid once
-    // per stage, under the commit, instead of once per tap inside the MFMA loop.
-    // Only in the small-tile configurations (picked for small volumes, where a block's life is latency, not throughput):
-    // on the 128^3 layers the extra VGPRs cost occupancy (measured 0.119 -> 0.181 ms on 32->16).
-    constexpr bool WREG = KSTEPS * NT <= 28 && BZ * BY * BX <= 128;
-    bf16x8 wall[WREG ? KSTEPS : 1][NT];
 
     if (nst > 0) prefetch(0);
     for (int st = 0; st < nst; ++st) {
         const int k = st / nchunk, q = st - k * nchunk;
         const bf16x8* wq = wp + ((size_t)q * KSTEPS * NTT + nt0) * 64 + lane;
-        if (WREG) {
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) wall[ks][n] = wq[((size_t)ks * NTT + n) * 64];
-        }
         __syncthreads();                 // every wave is done reading the previous stage's tile
         commit(st);
         __syncthreads();
         if (st + 1 < nst) prefetch(st + 1);   // in flight during the MFMAs below
 
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            bf16x8 wf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) wf[n] = WREG ? wall[ks][n] : wq[((size_t)ks * NTT + n) * 64];
-            int toff;
-            if (CK == 32) {
-                toff = (((ks / (KD * KD)) * HY + (ks / KD) % KD) * HX + ks % KD) * VS;
-            } else {
+        // Tap loop, software-pipelined by hand: the LDS reads (patches + filter fragments) of tap ks+1 are issued before
+        // the MFMAs of tap ks and the order is pinned with sched_barrier -- left to itself hipcc placed every ds_read one
+        // instruction ahead of its MFMA (s_waitcnt lgkmcnt(1) per MFMA: one LDS latency per 16-cycle MFMA).
+        auto tap_off = [&](int ks, int& toff, int& kxs) {
+            kxs = 0;
+            if (SWZ) { toff = ((ks / 9) * HY + (ks / 3) % 3) * HXP * 64; kxs = ks % 3; }
+            else if (CK == 32) toff = (((ks / (KD * KD)) * HY + (ks / KD) % KD) * HX + ks % KD) * VS;
+            else {
                 const int t0 = 2 * ks, t1 = 2 * ks + 1 < T ? 2 * ks + 1 : 2 * ks;
                 const int o0 = (((t0 / (KD * KD)) * HY + (t0 / KD) % KD) * HX + t0 % KD) * VS;
                 const int o1 = (((t1 / (KD * KD)) * HY + (t1 / KD) % KD) * HX + t1 % KD) * VS;
                 toff = (lane & 32) ? o1 : o0;
             }
+        };
+        bf16x8 xbuf[2][MTW], wbuf[2][NT];
+        auto load_tap = [&](int ks, int slot) {
+            int toff, kxs;
+            tap_off(ks, toff, kxs);
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                bf16x8 xb = *(const bf16x8*)(smem + mbase[i] + toff);
+            for (int n = 0; n < NT; ++n)
+                wbuf[slot][n] = WLDS ? *(const bf16x8*)(smem + TILE_B + ((ks * NT + n) * 64 + lane) * 16) : wq[((size_t)ks * NTT + n) * 64];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xb, acc[i][n], 0, 0, 0);
-            }
+            for (int i = 0; i < MTW; ++i) xbuf[slot][i] = *(const bf16x8*)(smem + mbase[i][SWZ ? kxs : 0] + toff);
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if (ks + 1 < KSTEPS) load_tap(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbuf[ks & 1][n], xbuf[ks & 1][i], acc[i][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (q != nchunk - 1) continue;
 
@@ -504,7 +549,7 @@ __global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
             if (tid < NT * 16) {
                 float u = 0.f, v = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
+                for (int w = 0; w < NW; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
                 int c = nt0 * 16 + tid;
                 a.stats[((size_t)bid * g.Cout + c) * 2 + 0] = u;
                 a.stats[((size_t)bid * g.Cout + c) * 2 + 1] = v;
@@ -516,25 +561,32 @@ __global__ void __launch_bounds__(256) k_mfma_conv_p(MfmaConvArgs a) {
 // ---- launch plumbing ----
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
 static void launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
+    constexpr int NW = (BZ * BY * BX / 16) % 8 == 0 && BZ * BY * BX >= 256 ? 8 : 4;   // waves per block
     MfmaConvArgs a = a0;
     a.tiles_x = (a.g.Wo + BX - 1) / BX; a.tiles_y = (a.g.Ho + BY - 1) / BY; a.tiles_z = (a.g.Do + BZ - 1) / BZ;
-    constexpr int VS = CK == 32 ? 96 : 32;
-    constexpr size_t lds = (size_t)((BZ - 1) * S + KD) * ((BY - 1) * S + KD) * ((BX - 1) * S + KD) * VS;
-    static_assert(lds >= 4 * NT * 16 * 2 * 4, "stats scratch must fit the tile buffer");
+    constexpr bool SWZ = CK == 32 && S == 1 && KD == 3;
+    constexpr int VS = SWZ ? 64 : (CK == 32 ? 96 : 32);
+    constexpr int HXr = (BX - 1) * S + KD, HXP = SWZ ? (HXr + 3) / 4 * 4 : HXr;
+    constexpr int T = KD * KD * KD, KSTEPS = CK == 32 ? T : (T + 1) / 2;
+    constexpr size_t tile_b = (size_t)((BZ - 1) * S + KD) * ((BY - 1) * S + KD) * HXP * VS;
+    constexpr size_t lds = tile_b + (KSTEPS * NT <= 32 ? (size_t)KSTEPS * NT * 1024 : 0);
+    static_assert(tile_b >= NW * NT * 16 * 2 * 4, "stats scratch must fit the tile buffer");
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     // persistent grid: at most ~2 blocks per CU in total (256 CUs), tiles strided over them
     const int tiles = a.tiles_x * a.tiles_y * a.tiles_z, gy = a.g.Cout / (16 * NT);
-    constexpr int bpc = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : 2);   // resident blocks per CU the LDS tile allows (cap 4)
-    int gx = bpc * 256 / gy;
+    // resident blocks per CU the LDS footprint allows, as a power of two (768-block grids measured 25 % slower than 512 / 1024)
+    constexpr int bpc = (lds <= 40 * 1024 && NW == 4) ? 4 : 2;
+    static const int bpc_env = getenv("UNET_CONV_BPC") ? atoi(getenv("UNET_CONV_BPC")) : 0;   // experiment knob
+    int gx = (bpc_env > 0 ? bpc_env : bpc) * 256 / gy;
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC><<<grid, 256, lds, s>>>(a);
+    k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW><<<grid, NW * 64, lds, s>>>(a);
 }
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> static void launch_nt(const MfmaConvArgs& a, hipStream_t s) {
     int ntt = a.g.Cout / 16;
@@ -544,6 +596,8 @@ template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> stati
         // row tiles per block: as many as divide the row count, fewer when the grid would not fill the 256 CUs
         int tiles = ((a.g.Wo + BX - 1) / BX) * ((a.g.Ho + BY - 1) / BY) * ((a.g.Do + BZ - 1) / BZ);
         int nt = ntt % 4 == 0 ? 4 : (ntt % 2 == 0 ? 2 : 1);
+        constexpr int T = KD * KD * KD, KSTEPS = CK == 32 ? T : (T + 1) / 2;
+        while (nt > 1 && KSTEPS * nt > 32) nt >>= 1;            // keep the chunk's filter fragments LDS-resident
         while (nt > 1 && (int64_t)tiles * (ntt / nt) < 256) nt >>= 1;
         if (nt == 4) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
         else if (nt == 2) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
