@@ -92,50 +92,61 @@ __global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
     const int actb = a.bsrc.act;
     const bool do_bias = a.bias_slab != nullptr && ciB == 0;
 
+    // staging units of this thread, decoded once (coordinates packed 10 bits each, -1 = none; LDS byte offsets)
+    constexpr int UNITS_A = NVA * GA, ITERS_A = (UNITS_A + 255) / 256;
+    constexpr int UNITS_B = NVB * GB, ITERS_B = (UNITS_B + 255) / 256;
+    int ua_coord[ITERS_A], ua_lds[ITERS_A], ub_coord[ITERS_B], ub_lds[ITERS_B];
+#pragma unroll
+    for (int itr = 0; itr < ITERS_A; ++itr) {
+        const int u = tid + itr * 256, hv = u / GA;
+        const int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
+        ua_coord[itr] = u < UNITS_A ? (hz | (hy << 10) | (hx << 20)) : -1;
+        ua_lds[itr] = (ua >> 1) * PLANE_A + hv * 32 + (ua & 1) * 16;
+    }
+#pragma unroll
+    for (int itr = 0; itr < ITERS_B; ++itr) {
+        const int u = tid + itr * 256, tv = u / GB;
+        const int tz = tv / (BY * BX), tr = tv % (BY * BX), ty = tr / BX, tx = tr % BX;
+        ub_coord[itr] = u < UNITS_B ? (tz | (ty << 10) | (tx << 20)) : -1;
+        ub_lds[itr] = B_OFF + (ub >> 1) * PLANE_B + tv * 32 + (ub & 1) * 16;
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ox0 = (tile % a.tiles_x) * BX, oy0 = ((tile / a.tiles_x) % a.tiles_y) * BY, oz0 = (tile / (a.tiles_x * a.tiles_y)) * BZ;
         const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD, iz0 = oz0 * S - PAD;
         __syncthreads();
-        // ---- stage A: halo tile ----
+        // ---- stage A: halo tile (units decoded once per thread: ua_coord / ua_lds) ----
         {
-            constexpr int UNITS = NVA * GA, ITERS = (UNITS + 255) / 256;
-#pragma unroll 4
-            for (int itr = 0; itr < ITERS; ++itr) {
-                int u = tid + itr * 256;
-                if (u < UNITS) {
-                    int hv = u / GA;
-                    int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
-                    int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+            const size_t vstride = (size_t)sd.C * 2;
+#pragma unroll
+            for (int itr = 0; itr < ITERS_A; ++itr) {
+                const int uc = ua_coord[itr];
+                if (uc >= 0) {
+                    const int gz = iz0 + (uc & 1023), gy = iy0 + ((uc >> 10) & 1023), gx = ix0 + (uc >> 20);
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
-                        size_t vox = ((size_t)gz * g.H + gy) * g.W + gx;
-                        v = transform8(*(const uint4*)(abase + vox * (size_t)sd.C * 2), xf, sc, sh, act);
-                    }
-                    *(uint4*)(smem + (ua >> 1) * PLANE_A + hv * 32 + (ua & 1) * 16) = v;
+                    if ((unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
+                        v = transform8(*(const uint4*)(abase + (((size_t)gz * g.H + gy) * g.W + gx) * vstride), xf, sc, sh, act);
+                    *(uint4*)(smem + ua_lds[itr]) = v;
                 }
             }
         }
         // ---- stage B: tile (+ bias partial sums of the raw values) ----
         {
-            constexpr int UNITS = NVB * GB, ITERS = (UNITS + 255) / 256;
-#pragma unroll 4
-            for (int itr = 0; itr < ITERS; ++itr) {
-                int u = tid + itr * 256;
-                if (u < UNITS) {
-                    int tv = u / GB;
-                    int tz = tv / (BY * BX), tr = tv % (BY * BX), ty = tr / BX, tx = tr % BX;
-                    int gz = oz0 + tz, gy = oy0 + ty, gx = ox0 + tx;
+            const size_t vstride = (size_t)g.Cout * 2;
+#pragma unroll
+            for (int itr = 0; itr < ITERS_B; ++itr) {
+                const int uc = ub_coord[itr];
+                if (uc >= 0) {
+                    const int gz = oz0 + (uc & 1023), gy = oy0 + ((uc >> 10) & 1023), gx = ox0 + (uc >> 20);
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
                     if (gz < g.Do && gy < g.Ho && gx < g.Wo) {
-                        size_t vox = ((size_t)gz * g.Ho + gy) * g.Wo + gx;
-                        v = *(const uint4*)(bbase + vox * (size_t)g.Cout * 2);
+                        v = *(const uint4*)(bbase + (((size_t)gz * g.Ho + gy) * g.Wo + gx) * vstride);
                         if (do_bias) {
                             bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
                             bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
                         }
                         v = transform8(v, xfb, scb, shb, actb);
                     }
-                    *(uint4*)(smem + B_OFF + (ub >> 1) * PLANE_B + tv * 32 + (ub & 1) * 16) = v;
+                    *(uint4*)(smem + ub_lds[itr]) = v;
                 }
             }
         }
