@@ -299,7 +299,8 @@ static void run_pack(const float* w, void* out, int Ci, int Co, int CK, int T, i
 // a block's lifetime in MFMAs, the rest waiting for the halo tile).
 // ------------------------------------------------------------------------------------------------
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC, int NW>
-__global__ void __launch_bounds__(NW * 64) k_mfma_conv_p(MfmaConvArgs a) {
+// launch bounds: 2 resident blocks per CU (4 waves/SIMD, <= 128 VGPRs) for the 8-wave light configurations, else 2 waves/SIMD (<= 256)
+__global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_conv_p(MfmaConvArgs a) {
     constexpr int NTHR = NW * 64;   // 8 waves on the larger tiles: half the staging registers per thread, 4 waves per SIMD at 2 blocks/CU
     constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD, NVOX = HZ * HY * HX;
     constexpr int G = CK / 8;

@@ -38,7 +38,7 @@ __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
 }
 
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int PI, int PJ>
-__global__ void __launch_bounds__(256) k_mfma_wgrad(MfmaWgradArgs a) {
+__global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <= 256 VGPRs: two blocks per CU
     constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD;
     constexpr int NVA = HZ * HY * HX, NVB = BZ * BY * BX, T = KD * KD * KD;
     constexpr int PLANE_A = NVA * 32, PLANE_B = NVB * 32, B_OFF = PI * PLANE_A;
