@@ -118,6 +118,14 @@ int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const
 int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* scale, const float* shift, int act, const float* w,
                              const float* b, void* y, float* stats, int cin, int cout, int D, int H, int W, int ks, int stride,
                              void* scratch, void* stream);
+/* The two halves of unet_op_conv3d_fwd_fused as a plan runs them (unet_forward packs every filter once per call, then
+ * launches one kernel per torch::nn::Conv3d, unet.cpp:59-72): pack the fp32 filter into MFMA fragment order, then launch
+ * ONLY the convolution kernel.  wpacked and stats_partials (may be NULL; per-block {sum, sum of squares} partials of the
+ * stored output) each need unet_op_scratch_bytes() bytes.  Fails for shapes the MFMA kernels do not cover. */
+int unet_op_conv3d_pack(int dtype, const float* w, void* wpacked, int cin, int cout, int D, int H, int W, int ks, int stride,
+                        void* stream);
+int unet_op_conv3d_fwd_packed(int dtype, const void* x, const void* wpacked, const float* b, void* y, float* stats_partials,
+                              int cin, int cout, int D, int H, int W, int ks, int stride, void* stream);
 int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H,
                             int W, int ks, int stride, void* scratch, void* stream);
 int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy, float* dw, float* db, int cin, int cout,

@@ -61,6 +61,9 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     (128, 64, (4, 4, 4), 3, 1), (16, 16, (3, 5, 7), 3, 1), (32, 16, (16, 16, 32), 3, 1),
     # stride-2 MFMA wgrad: every tile configuration (Wo >= 12, 5..11, <= 4), PJ 1/2/4, odd input sizes
     (16, 32, (12, 16, 32), 3, 2), (32, 64, (9, 11, 13), 3, 2), (64, 16, (8, 8, 8), 3, 2), (16, 16, (5, 7, 25), 3, 2),
+    # register-accumulating small wgrads: first conv (Cin = 1; W % 4 != 0 falls back to the row kernel) and 1x1x1 heads
+    (1, 8, (6, 5, 8), 3, 1), (1, 16, (5, 6, 7), 3, 1), (1, 32, (17, 9, 16), 3, 1), (64, 6, (4, 5, 6), 1, 1), (256, 6, (3, 4, 5), 1, 1),
+    (32, 3, (5, 6, 7), 1, 1), (16, 8, (33, 8, 9), 1, 1),
 ]
 
 
@@ -97,6 +100,25 @@ def test_conv3d_ops(case, dt, impl):
                                             D, H, W, ks, st, sc.data_ptr(), stream()))
     assert rel(dwd.cpu().numpy() - 1.0, dw_ref) < (2e-5 if dt == "fp32" else 1e-2)
     assert rel(dbd.cpu().numpy() - 1.0, db_ref) < (2e-5 if dt == "fp32" else 1e-2)
+
+
+def test_conv3d_pack_then_kernel_only():
+    """unet_op_conv3d_pack + unet_op_conv3d_fwd_packed (what bench.py times as the dominant kernel) = unet_op_conv3d_fwd;
+    shapes the MFMA kernels do not cover are refused"""
+    cin, cout, D, H, W = 32, 16, 6, 9, 20
+    l = O.lib()
+    x = q(rnd((cin, D, H, W), 1), "bf16"); w = rnd((cout, cin, 3, 3, 3), 2, 0.2); b = rnd((cout,), 3)
+    y_ref = np.empty((cout, D, H, W), np.float32)
+    l.orc_conv3d_fwd(O._f(x), O._f(w), O._f(b), O._f(y_ref), cin, cout, D, H, W, 3, 1)
+    wp, part = scratch(cin, cout, D, H, W), scratch(cin, cout, D, H, W)
+    wd, bd, xd = torch.from_numpy(w).to(DEV), torch.from_numpy(b).to(DEV), to_cl(x, "bf16")
+    yd = torch.empty((D, H, W, cout), dtype=torch.bfloat16, device=DEV)
+    E.check(E.lib.unet_op_conv3d_pack(U.DTYPE_BF16, wd.data_ptr(), wp.data_ptr(), cin, cout, D, H, W, 3, 1, stream()))
+    E.check(E.lib.unet_op_conv3d_fwd_packed(U.DTYPE_BF16, xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), yd.data_ptr(), part.data_ptr(),
+                                            cin, cout, D, H, W, 3, 1, stream()))
+    assert rel(from_cl(yd), y_ref) < 1e-2
+    assert E.lib.unet_op_conv3d_pack(U.DTYPE_F32, wd.data_ptr(), wp.data_ptr(), cin, cout, D, H, W, 3, 1, stream()) != 0
+    assert b"MFMA" in E.lib.unet_last_error()
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])

@@ -167,7 +167,7 @@ struct unet_plan {
             ConvGeom cg = op_geom_of(op);
             size_t b = wgrad_direct_scratch_bytes(cg, op.kind == OP_CONVT);
             if (b > wmax) wmax = b;
-            if (op.kind == OP_CONV && wgrad_small_supported(cg)) {
+            if (op.kind == OP_CONV && wgrad_small_supported(cg, op.nsrc)) {
                 b = wgrad_small_scratch_bytes(cg);
                 if (b > wmax) wmax = b;
             }
@@ -406,7 +406,7 @@ struct Exec {
                     if (op.kind == OP_CONV) {
                         if (p.wgrad_mfma[i])
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
-                        else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg))
+                        else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
                             launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
                         else
                             launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
@@ -696,6 +696,10 @@ int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes)
         size_t w = ((size_t)1024 * 1024 + (size_t)1024 * cout) * 4 + 1024;
         if (w > b) b = w;
     }
+    if (cout <= 8 || cin == 1) {   // register-accumulating small wgrads: <= 512 blocks x (weights + bias sums)
+        size_t w = (size_t)512 * ((size_t)27 * cin * cout + cout) * 4 + 1024;
+        if (w > b) b = w;
+    }
     if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {
         ConvGeom g;   // MFMA wgrad slabs: stride-1 geometry has the most tiles
         g.Cin = cin; g.Cout = cout; g.D = g.Do = D; g.H = g.Ho = H; g.W = g.Wo = W; g.ks = 3; g.stride = 1;
@@ -774,6 +778,24 @@ int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* sc
         }
     })
 }
+int unet_op_conv3d_pack(int dtype, const float* w, void* wpacked, int cin, int cout, int D, int H, int W, int ks, int stride,
+                        void* stream) {
+    OP_TRY({
+        ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
+        SrcDesc sd; sd.C = cin;
+        if (!mfma_conv_fwd_supported(dtype, g, &sd, 1)) throw std::runtime_error("unet_op_conv3d_pack: shape not covered by the MFMA kernels");
+        launch_mfma_pack_conv_w(w, wpacked, nullptr, g, (hipStream_t)stream);
+    })
+}
+int unet_op_conv3d_fwd_packed(int dtype, const void* x, const void* wpacked, const float* b, void* y, float* stats_partials,
+                              int cin, int cout, int D, int H, int W, int ks, int stride, void* stream) {
+    OP_TRY({
+        ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
+        SrcDesc sd; sd.ptr = x; sd.C = cin;
+        if (!mfma_conv_fwd_supported(dtype, g, &sd, 1)) throw std::runtime_error("unet_op_conv3d_fwd_packed: shape not covered by the MFMA kernels");
+        launch_mfma_conv_fwd(g, &sd, 1, wpacked, b, y, stats_partials, (hipStream_t)stream);
+    })
+}
 int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w, void* dx, int cin, int cout, int D, int H, int W,
                             int ks, int stride, void* scratch, void* stream) {
     OP_TRY({
@@ -799,7 +821,7 @@ int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy
         SrcDesc sd; sd.ptr = x; sd.C = cin;
         if (impl == UNET_IMPL_AUTO && mfma_wgrad_supported(dtype, g, &sd, 1))
             launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
-        else if (impl == UNET_IMPL_AUTO && wgrad_small_supported(g))
+        else if (impl == UNET_IMPL_AUTO && wgrad_small_supported(g, 1))
             launch_conv_wgrad_small(dtype, g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
         else
             launch_conv_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);

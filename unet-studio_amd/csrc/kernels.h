@@ -139,7 +139,7 @@ size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s);
 // wgrad of layers with <= 1024 weights (Cin = 1 first conv, 6-channel heads): row-staged, HBM-bound
-bool wgrad_small_supported(const ConvGeom& g);
+bool wgrad_small_supported(const ConvGeom& g, int nsrc);
 size_t wgrad_small_scratch_bytes(const ConvGeom& g);
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
                              void* scratch, hipStream_t s);

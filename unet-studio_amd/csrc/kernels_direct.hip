@@ -325,7 +325,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(Wgra
 
 // out[i] += sum_k slab[k][i]   (fixed order: deterministic)
 // a block = 32 consecutive outputs x 8 split lanes: coalesced slab reads, 8 lanes share each output's split loop
-__global__ void __launch_bounds__(256) k_slab_reduce_k(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_slab_reduce_k(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out,
+                                                       int64_t n1, float* __restrict__ out2) {
     __shared__ double red[8][32];
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int64_t i = (int64_t)blockIdx.x * 32 + lx;
@@ -338,11 +339,16 @@ __global__ void __launch_bounds__(256) k_slab_reduce_k(const float* __restrict__
         double tot = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) tot += red[k][lx];
-        out[i] += (float)tot;
+        if (i < n1) out[i] += (float)tot;
+        else if (out2) out2[i - n1] += (float)tot;
     }
 }
 static void slab_reduce(const float* slab, int nsplit, int64_t n, float* out, hipStream_t s) {
-    k_slab_reduce_k<<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out);
+    k_slab_reduce_k<<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out, n, nullptr);
+}
+// outputs [0,n1) go to out, [n1,n) to out2 (skipped when out2 is null)
+static void slab_reduce2(const float* slab, int nsplit, int64_t n, float* out, int64_t n1, float* out2, hipStream_t s) {
+    k_slab_reduce_k<<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out, n1, out2);
 }
 
 // bias grad: db[c] += sum over voxels of dy[v][c]; one block per channel
@@ -580,25 +586,217 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_small(Wgrad
     }
 }
 
-static int wgrad_small_blocks(const ConvGeom& g) { int rows = g.Do * g.Ho; return rows < 1024 ? rows : 1024; }
-bool wgrad_small_supported(const ConvGeom& g) {
+// ---- register-accumulating small wgrads -----------------------------------------------------------------------------
+// Few weights, many voxels (the 1x1x1 heads, the Cin=1 first conv): a thread owns a slice of the weights (a "chunk") and keeps
+// its accumulators in registers while it streams voxels; lanes that own the same chunk are summed with xor-shuffles, waves
+// through LDS, blocks through the slab (fixed order everywhere).
+template <int NACC, typename F>
+__device__ __forceinline__ void small_wgrad_epilogue(float (&acc)[NACC], int nchunk, float* sm, float* slab_row, F omap) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        float v = acc[a];
+        for (int m = 32; m >= nchunk; m >>= 1) v += __shfl_xor(v, m);
+        acc[a] = v;
+    }
+    if (lane < nchunk) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) sm[(wave * nchunk + lane) * NACC + a] = acc[a];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nchunk * NACC; i += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += sm[w * nchunk * NACC + i];
+        int o = omap(i / NACC, i % NACC);
+        if (o >= 0) slab_row[o] = t;
+    }
+}
+
+struct WgradRegArgs {
+    ConvGeom g;
+    SrcDesc src;
+    const void* dy;
+    float* slab;      // [gridDim.x][O + Cout]  (bias sums appended)
+    int lc;           // log2(chunks per voxel)
+};
+
+// 1x1x1 conv, Cout <= CO <= 8, Cin = 16 * 2^lc: a thread owns 16 input channels x all outputs
+template <typename T, int CO> __global__ void __launch_bounds__(256) k_wgrad_head(WgradRegArgs a) {
+    extern __shared__ float sm[];
+    constexpr int NACC = CO * 16 + CO;
+    const ConvGeom& g = a.g;
+    const int nchunk = 1 << a.lc, chunk = threadIdx.x & (nchunk - 1), c0 = chunk * 16;
+    const int64_t S = (int64_t)g.D * g.H * g.W;
+    const int64_t vstride = ((int64_t)gridDim.x * 256) >> a.lc;
+    const T* dy = (const T*)a.dy;
+    const bool plain = !a.src.scale && a.src.act == 0;
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    for (int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc; v0 < S; v0 += 4 * vstride) {
+        float xs[4][16], ds[4][CO];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t v = v0 + u * vstride;
+            const bool ok = v < S;
+            if constexpr (sizeof(T) == 2) {
+                if (plain) {
+                    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+                    if (ok) {
+                        const uint4* q = (const uint4*)((const bf16*)a.src.ptr + v * a.src.C + c0);
+                        r0 = q[0]; r1 = q[1];
+                    }
+                    const unsigned w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { xs[u][2 * k] = __uint_as_float(w[k] << 16); xs[u][2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) xs[u][k] = ok ? view_ld<T>(a.src, v, c0 + k) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xs[u][k] = ok ? view_ld<T>(a.src, v, c0 + k) : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < CO; ++c) ds[u][c] = (ok && c < g.Cout) ? ld<T>(dy, v * g.Cout + c) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[c * 16 + k] = fmaf(ds[u][c], xs[u][k], acc[c * 16 + k]);
+                acc[CO * 16 + c] += ds[u][c];
+            }
+        }
+    }
+    const int Cin = g.Cin, Cout = g.Cout, O = Cin * Cout;
+    small_wgrad_epilogue<NACC>(acc, nchunk, sm, a.slab + (int64_t)blockIdx.x * (O + Cout), [=](int ch, int i) {
+        if (i < CO * 16) { int c = i / 16, k = i % 16; return c < Cout ? c * Cin + ch * 16 + k : -1; }
+        int c = i - CO * 16;
+        return (ch == 0 && c < Cout) ? O + c : -1;
+    });
+}
+
+// 3x3x3 stride-1 conv with Cin = 1, Cout = 4 * 2^lc: a thread owns 4 outputs x 27 taps and walks runs of 4 voxels along x
+template <typename T> __global__ void __launch_bounds__(256) k_wgrad_first(WgradRegArgs a) {
+    extern __shared__ float sm[];
+    constexpr int NACC = 27 * 4 + 4;
+    const ConvGeom& g = a.g;
+    const int nchunk = 1 << a.lc, chunk = threadIdx.x & (nchunk - 1), co0 = chunk * 4;
+    const int W4 = g.W >> 2;
+    const int64_t runs = (int64_t)g.D * g.H * W4;
+    const int64_t rstride = ((int64_t)gridDim.x * 256) >> a.lc;
+    const T* dy = (const T*)a.dy;
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc; r < runs; r += rstride) {
+        const int x0 = (int)(r % W4) * 4;
+        const int y = (int)((r / W4) % g.H), z = (int)(r / ((int64_t)W4 * g.H));
+        float in[3][3][6], ds[4][4];
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iz = z + kz - 1, iy = y + ky - 1;
+                const bool rok = iz >= 0 && iz < g.D && iy >= 0 && iy < g.H;
+                const int64_t base = ((int64_t)iz * g.H + iy) * g.W;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int ix = x0 + k - 1;
+                    in[kz][ky][k] = (rok && ix >= 0 && ix < g.W) ? view_ld<T>(a.src, base + ix, 0) : 0.f;
+                }
+            }
+        const int64_t vox = ((int64_t)z * g.H + y) * g.W + x0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ds[u][c] = ld<T>(dy, (vox + u) * g.Cout + co0 + c);
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[((kz * 3 + ky) * 3 + kx) * 4 + c] = fmaf(in[kz][ky][u + kx], ds[u][c], acc[((kz * 3 + ky) * 3 + kx) * 4 + c]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[108 + c] += ds[u][c];
+    }
+    const int Cout = g.Cout, O = 27 * Cout;
+    small_wgrad_epilogue<NACC>(acc, nchunk, sm, a.slab + (int64_t)blockIdx.x * (O + Cout), [=](int ch, int i) {
+        if (i < 108) return (ch * 4 + i % 4) * 27 + i / 4;      // torch layout [co][ci=0][tap]
+        return O + ch * 4 + (i - 108);
+    });
+}
+
+static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+static bool wgrad_head_ok(const ConvGeom& g, int nsrc) {
+    return nsrc == 1 && g.ks == 1 && g.stride == 1 && g.Cout <= 8 && g.Cin % 16 == 0 && ilog2_exact(g.Cin / 16) >= 0 && g.Cin <= 256;
+}
+static bool wgrad_first_ok(const ConvGeom& g, int nsrc) {
+    return nsrc == 1 && g.ks == 3 && g.stride == 1 && g.Cin == 1 && g.Cout % 4 == 0 && ilog2_exact(g.Cout / 4) >= 0 && g.Cout <= 64 &&
+           g.W % 4 == 0;
+}
+static int wgrad_reg_blocks(int64_t items) { int64_t nb = (items + 1023) / 1024; return nb < 1 ? 1 : (nb > 512 ? 512 : (int)nb); }
+static bool wgrad_rows_ok(const ConvGeom& g) {
     int k3 = g.ks * g.ks * g.ks;
     int WI = (g.Wo - 1) * g.stride + g.ks;
     size_t lds = ((size_t)g.ks * g.ks * WI * g.Cin + (size_t)g.Wo * g.Cout) * 4;
     return (int64_t)k3 * g.Cin * g.Cout <= 1024 && lds <= 48 * 1024;
 }
+
+static int wgrad_small_blocks(const ConvGeom& g) { int rows = g.Do * g.Ho; return rows < 1024 ? rows : 1024; }
+bool wgrad_small_supported(const ConvGeom& g, int nsrc) { return wgrad_head_ok(g, nsrc) || wgrad_first_ok(g, nsrc) || wgrad_rows_ok(g); }
 size_t wgrad_small_scratch_bytes(const ConvGeom& g) {
     int k3 = g.ks * g.ks * g.ks;
     int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
-    return (size_t)wgrad_small_blocks(g) * k3 * g.Cin * g.Cout * 4 + bias_grad_scratch_bytes(g.Cout, So) + 256;
+    size_t O = (size_t)k3 * g.Cin * g.Cout;
+    size_t rows = (size_t)wgrad_small_blocks(g) * O * 4 + bias_grad_scratch_bytes(g.Cout, So) + 256;
+    size_t regs = (size_t)512 * (O + g.Cout) * 4 + 256;
+    return rows > regs ? rows : regs;
 }
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
                              void* scratch, hipStream_t s) {
+    const int k3 = g.ks * g.ks * g.ks;
+    const int64_t O = (int64_t)k3 * g.Cin * g.Cout;
+    const bool head = wgrad_head_ok(g, nsrc), first = !head && wgrad_first_ok(g, nsrc);
+    if (head || first) {
+        WgradRegArgs a;
+        a.g = g; a.src = src[0]; a.dy = dy; a.slab = (float*)scratch;
+        const int64_t S = (int64_t)g.D * g.H * g.W;
+        int nb;
+        if (head) {
+            a.lc = ilog2_exact(g.Cin / 16);
+            nb = wgrad_reg_blocks((S << a.lc) / 4);
+            const int CO = g.Cout <= 2 ? 2 : g.Cout <= 4 ? 4 : g.Cout <= 6 ? 6 : 8;
+            const size_t lds = (size_t)4 * (1 << a.lc) * (CO * 17) * 4;
+            switch (CO) {
+                case 2: UNET_DISPATCH(dtype, (k_wgrad_head<T, 2><<<nb, 256, lds, s>>>(a))); break;
+                case 4: UNET_DISPATCH(dtype, (k_wgrad_head<T, 4><<<nb, 256, lds, s>>>(a))); break;
+                case 6: UNET_DISPATCH(dtype, (k_wgrad_head<T, 6><<<nb, 256, lds, s>>>(a))); break;
+                default: UNET_DISPATCH(dtype, (k_wgrad_head<T, 8><<<nb, 256, lds, s>>>(a))); break;
+            }
+        } else {
+            a.lc = ilog2_exact(g.Cout / 4);
+            nb = wgrad_reg_blocks(((S / 4) << a.lc));
+            const size_t lds = (size_t)4 * (1 << a.lc) * 112 * 4;
+            UNET_DISPATCH(dtype, (k_wgrad_first<T><<<nb, 256, lds, s>>>(a)));
+        }
+        slab_reduce2(a.slab, nb, O + g.Cout, dw, O, db, s);
+        return;
+    }
     WgradSmallArgs a;
     a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
     a.dy = dy; a.slab = (float*)scratch;
-    int nb = wgrad_small_blocks(g), k3 = g.ks * g.ks * g.ks;
-    int64_t O = (int64_t)k3 * g.Cin * g.Cout;
+    int nb = wgrad_small_blocks(g);
     int WI = (g.Wo - 1) * g.stride + g.ks;
     size_t lds = ((size_t)g.ks * g.ks * WI * g.Cin + (size_t)g.Wo * g.Cout) * 4;
     UNET_DISPATCH(dtype, (k_wgrad_small<T><<<nb, 256, lds, s>>>(a)));

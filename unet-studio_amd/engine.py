@@ -55,6 +55,8 @@ _sig("unet_loss", _i, _vp, _pp, _vp, _i, _i, _pp, _vp, _vp, _vp)
 _sig("unet_sgd_step", _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _f, _vp, _vp, _vp)
 _sig("unet_op_scratch_bytes", _i, _i, _i, _i, _i, _i, C.POINTER(_sz))
 _sig("unet_op_conv3d_fwd", _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
+_sig("unet_op_conv3d_pack", _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp)
+_sig("unet_op_conv3d_fwd_packed", _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp)
 _sig("unet_op_conv3d_fwd_fused", _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
 _sig("unet_op_conv3d_bwd_data", _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
 _sig("unet_op_conv3d_bwd_weight", _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
@@ -70,7 +72,7 @@ EXPORTS = [
     "unet_plan_param_shape", "unet_plan_param_name", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
     "unet_plan_buffer_shape", "unet_plan_output_count", "unet_plan_output_shape", "unet_plan_workspace_bytes",
     "unet_plan_flops", "unet_plan_describe", "unet_forward", "unet_backward", "unet_loss_scratch_bytes", "unet_loss",
-    "unet_sgd_step", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
+    "unet_sgd_step", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_pack", "unet_op_conv3d_fwd_packed", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
     "unet_op_convt_fwd", "unet_op_convt_bwd_data", "unet_op_convt_bwd_weight", "unet_op_pack_ndhwc", "unet_op_unpack_ncdhw",
 ]
 
