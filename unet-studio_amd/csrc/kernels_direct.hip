@@ -324,32 +324,32 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_direct(Wgra
 }
 
 // out[i] += sum_k slab[k][i]   (fixed order: deterministic)
-// a block = 32 consecutive outputs x 8 split lanes: coalesced slab reads, 8 lanes share each output's split loop
-__global__ void __launch_bounds__(256) k_slab_reduce_k(const float* __restrict__ slab, int nsplit, int64_t n, float* __restrict__ out,
-                                                       int64_t n1, float* __restrict__ out2) {
-    __shared__ double red[8][32];
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + lx;
+// a block = LX consecutive outputs x 256/LX split lanes: coalesced slab reads, the lanes of an output share its split loop
+template <int LX> __global__ void __launch_bounds__(256) k_slab_reduce_k(const float* __restrict__ slab, int nsplit, int64_t n,
+                                                                         float* __restrict__ out, int64_t n1, float* __restrict__ out2) {
+    constexpr int LY = 256 / LX;
+    __shared__ double red[LY][LX];
+    const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+    const int64_t i = (int64_t)blockIdx.x * LX + lx;
     double s = 0.0;
     if (i < n)
-        for (int k = ly; k < nsplit; k += 8) s += slab[(int64_t)k * n + i];
+        for (int k = ly; k < nsplit; k += LY) s += slab[(int64_t)k * n + i];
     red[ly][lx] = s;
     __syncthreads();
     if (ly == 0 && i < n) {
         double tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tot += red[k][lx];
+        for (int k = 0; k < LY; ++k) tot += red[k][lx];
         if (i < n1) out[i] += (float)tot;
         else if (out2) out2[i - n1] += (float)tot;
     }
 }
-static void slab_reduce(const float* slab, int nsplit, int64_t n, float* out, hipStream_t s) {
-    k_slab_reduce_k<<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out, n, nullptr);
-}
 // outputs [0,n1) go to out, [n1,n) to out2 (skipped when out2 is null)
 static void slab_reduce2(const float* slab, int nsplit, int64_t n, float* out, int64_t n1, float* out2, hipStream_t s) {
-    k_slab_reduce_k<<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out, n1, out2);
+    if (n <= 512 && nsplit >= 64) k_slab_reduce_k<4><<<cdiv64(n, 4), 256, 0, s>>>(slab, nsplit, n, out, n1, out2);
+    else k_slab_reduce_k<32><<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out, n1, out2);
 }
+static void slab_reduce(const float* slab, int nsplit, int64_t n, float* out, hipStream_t s) { slab_reduce2(slab, nsplit, n, out, n, nullptr, s); }
 
 // bias grad: db[c] += sum over voxels of dy[v][c]; one block per channel
 template <typename T> __global__ void __launch_bounds__(256) k_bias_grad(const T* __restrict__ dy, int C, int64_t S, float* db, float* slab) {
@@ -593,11 +593,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_small(Wgrad
 template <int NACC, typename F>
 __device__ __forceinline__ void small_wgrad_epilogue(float (&acc)[NACC], int nchunk, float* sm, float* slab_row, F omap) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = 32; m >= nchunk; m >>= 1) {   // all NACC shuffles of a step are independent: their latencies overlap
 #pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-        float v = acc[a];
-        for (int m = 32; m >= nchunk; m >>= 1) v += __shfl_xor(v, m);
-        acc[a] = v;
+        for (int a = 0; a < NACC; ++a) acc[a] += __shfl_xor(acc[a], m);
     }
     if (lane < nchunk) {
 #pragma unroll
@@ -679,57 +677,78 @@ template <typename T, int CO> __global__ void __launch_bounds__(256) k_wgrad_hea
     });
 }
 
-// 3x3x3 stride-1 conv with Cin = 1, Cout = 4 * 2^lc: a thread owns 4 outputs x 27 taps and walks runs of 4 voxels along x
+// 3x3x3 stride-1 conv with Cin = 1, Cout = 4 * 2^lc: a thread owns 4 outputs x 27 taps and walks runs of 4 voxels along x.
+// A block takes tiles of FIRST_TY output rows (all of x); the 3 x (FIRST_TY+2) input rows a tile touches are transformed once
+// into LDS as fp32 (zero halo), so a run's 3x3x6 window is nine 16-B + 8-B LDS reads.
+constexpr int FIRST_TY = 8;
 template <typename T> __global__ void __launch_bounds__(256) k_wgrad_first(WgradRegArgs a) {
     extern __shared__ float sm[];
     constexpr int NACC = 27 * 4 + 4;
     const ConvGeom& g = a.g;
     const int nchunk = 1 << a.lc, chunk = threadIdx.x & (nchunk - 1), co0 = chunk * 4;
-    const int W4 = g.W >> 2;
-    const int64_t runs = (int64_t)g.D * g.H * W4;
-    const int64_t rstride = ((int64_t)gridDim.x * 256) >> a.lc;
+    const int W4 = g.W >> 2, WP = (g.W + 2 + 3) & ~3;       // padded row pitch (floats), 16-B aligned runs
+    const int ytiles = (g.H + FIRST_TY - 1) / FIRST_TY, tiles = g.D * ytiles;
+    const int nin = 3 * (FIRST_TY + 2) * WP;
+    const int items = (FIRST_TY * W4) << a.lc;
     const T* dy = (const T*)a.dy;
     float acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
-    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc; r < runs; r += rstride) {
-        const int x0 = (int)(r % W4) * 4;
-        const int y = (int)((r / W4) % g.H), z = (int)(r / ((int64_t)W4 * g.H));
-        float in[3][3][6], ds[4][4];
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int z = tile / ytiles, y0 = (tile % ytiles) * FIRST_TY;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nin; i += 256) {
+            const int px = i % WP, r = i / WP, ry = r % (FIRST_TY + 2), rz = r / (FIRST_TY + 2);
+            const int iz = z + rz - 1, iy = y0 + ry - 1, ix = px - 1;
+            float v = 0.f;
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) v = view_ld<T>(a.src, ((int64_t)iz * g.H + iy) * g.W + ix, 0);
+            sm[i] = v;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int run = it >> a.lc, ty = run / W4, x0 = (run % W4) * 4;
+            if (y0 + ty >= g.H) continue;
+            float in[3][3][6], ds[4][4];
 #pragma unroll
-        for (int kz = 0; kz < 3; ++kz)
+            for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iz = z + kz - 1, iy = y + ky - 1;
-                const bool rok = iz >= 0 && iz < g.D && iy >= 0 && iy < g.H;
-                const int64_t base = ((int64_t)iz * g.H + iy) * g.W;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* row = sm + (kz * (FIRST_TY + 2) + ty + ky) * WP + x0;
+                    const float4 q = *(const float4*)row;
+                    const float2 q2 = *(const float2*)(row + 4);
+                    in[kz][ky][0] = q.x; in[kz][ky][1] = q.y; in[kz][ky][2] = q.z; in[kz][ky][3] = q.w;
+                    in[kz][ky][4] = q2.x; in[kz][ky][5] = q2.y;
+                }
+            const int64_t vox = ((int64_t)z * g.H + y0 + ty) * g.W + x0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    const int ix = x0 + k - 1;
-                    in[kz][ky][k] = (rok && ix >= 0 && ix < g.W) ? view_ld<T>(a.src, base + ix, 0) : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (sizeof(T) == 2) {
+                    const uint2 r = *(const uint2*)((const bf16*)dy + (vox + u) * g.Cout + co0);
+                    ds[u][0] = __uint_as_float(r.x << 16); ds[u][1] = __uint_as_float(r.x & 0xffff0000u);
+                    ds[u][2] = __uint_as_float(r.y << 16); ds[u][3] = __uint_as_float(r.y & 0xffff0000u);
+                } else {
+                    const float4 r = *(const float4*)((const float*)dy + (vox + u) * g.Cout + co0);
+                    ds[u][0] = r.x; ds[u][1] = r.y; ds[u][2] = r.z; ds[u][3] = r.w;
                 }
             }
-        const int64_t vox = ((int64_t)z * g.H + y) * g.W + x0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ds[u][c] = ld<T>(dy, (vox + u) * g.Cout + co0 + c);
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kz = 0; kz < 3; ++kz)
+                    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                        for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                            for (int c = 0; c < 4; ++c)
+                                acc[((kz * 3 + ky) * 3 + kx) * 4 + c] = fmaf(in[kz][ky][u + kx], ds[u][c], acc[((kz * 3 + ky) * 3 + kx) * 4 + c]);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[((kz * 3 + ky) * 3 + kx) * 4 + c] = fmaf(in[kz][ky][u + kx], ds[u][c], acc[((kz * 3 + ky) * 3 + kx) * 4 + c]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[108 + c] += ds[u][c];
+                for (int c = 0; c < 4; ++c) acc[108 + c] += ds[u][c];
+        }
     }
+    __syncthreads();
     const int Cout = g.Cout, O = 27 * Cout;
     small_wgrad_epilogue<NACC>(acc, nchunk, sm, a.slab + (int64_t)blockIdx.x * (O + Cout), [=](int ch, int i) {
         if (i < 108) return (ch * 4 + i % 4) * 27 + i / 4;      // torch layout [co][ci=0][tap]
@@ -743,7 +762,7 @@ static bool wgrad_head_ok(const ConvGeom& g, int nsrc) {
 }
 static bool wgrad_first_ok(const ConvGeom& g, int nsrc) {
     return nsrc == 1 && g.ks == 3 && g.stride == 1 && g.Cin == 1 && g.Cout % 4 == 0 && ilog2_exact(g.Cout / 4) >= 0 && g.Cout <= 64 &&
-           g.W % 4 == 0;
+           g.W % 4 == 0 && g.W <= 256;
 }
 static int wgrad_reg_blocks(int64_t items) { int64_t nb = (items + 1023) / 1024; return nb < 1 ? 1 : (nb > 512 ? 512 : (int)nb); }
 static bool wgrad_rows_ok(const ConvGeom& g) {
@@ -786,8 +805,10 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
             }
         } else {
             a.lc = ilog2_exact(g.Cout / 4);
-            nb = wgrad_reg_blocks(((S / 4) << a.lc));
-            const size_t lds = (size_t)4 * (1 << a.lc) * 112 * 4;
+            const int tiles = g.D * ((g.H + FIRST_TY - 1) / FIRST_TY);
+            nb = tiles < 512 ? tiles : 512;
+            const size_t l0 = (size_t)3 * (FIRST_TY + 2) * ((g.W + 5) & ~3) * 4, l1 = (size_t)4 * (1 << a.lc) * 112 * 4;
+            const size_t lds = l0 > l1 ? l0 : l1;
             UNET_DISPATCH(dtype, (k_wgrad_first<T><<<nb, 256, lds, s>>>(a)));
         }
         slab_reduce2(a.slab, nb, O + g.Cout, dw, O, db, s);
