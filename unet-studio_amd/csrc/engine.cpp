@@ -286,9 +286,9 @@ struct Exec {
                             launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         const Tensor& T = g.tensors[op.dst];
                         bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
-                        launch_mfma_conv_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst),
-                                             want_stats ? partial() : nullptr, s);
-                        if (want_stats) fused_blocks[T.norm] = mfma_conv_blocks(cg);
+                        int rows = launch_mfma_conv_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst),
+                                                        want_stats ? partial() : nullptr, s);
+                        if (want_stats) fused_blocks[T.norm] = rows;
                     } else if (op.kind == OP_CONV) {
                         launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
@@ -766,8 +766,8 @@ int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* sc
         if (impl == UNET_IMPL_AUTO && mfma_conv_fwd_supported(dtype, g, &sd, 1)) {
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_conv_w(w, wm, nullptr, g, s);
-            launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, stats ? part : nullptr, s);
-            if (stats) launch_stats_sum(part, mfma_conv_blocks(g), cout, stats, s);
+            int rows = launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, stats ? part : nullptr, s);
+            if (stats) launch_stats_sum(part, rows, cout, stats, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
             launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);

@@ -129,9 +129,10 @@ void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob*
 bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_conv_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
-void launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
-                          float* stats_partial, hipStream_t s);
-// number of thread blocks (= statistics partials) launch_mfma_conv_fwd uses for this geometry
+// returns the number of statistics partial rows written to stats_partial ([rows][Cout][2], one per persistent block)
+int launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
+                         float* stats_partial, hipStream_t s);
+// upper bound of that row count (tiles of the geometry): sizes the partials buffer
 int mfma_conv_blocks(const ConvGeom& g);
 // wgrad (+ bias grad) of a 3x3x3 conv, stride 1 or 2; dw/db fp32 torch layout, accumulated (+=); db may be nullptr
 bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);

@@ -439,6 +439,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
         }
     };
 
+    float s1[NT][4], s2[NT][4];      // per-thread norm statistics of the stored outputs (channels nt0*16 + n*16 + gq*4 + r)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; }
+
     if (nst > 0) prefetch(0);
     for (int st = 0; st < nst; ++st) {
         const int k = st / nchunk, q = st - k * nchunk;
@@ -489,11 +495,6 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
         // ---- tile epilogue ----
         const int bid = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, nblk);
         const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
-        float s1[NT][4], s2[NT][4];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             int c = (nt0 + n) * 16 + gq * 4;
@@ -533,38 +534,40 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
                 acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (!SC && a.stats) {
-            float* red = (float*)smem;
-            __syncthreads();                          // tile no longer needed (the next commit syncs again before writing)
+    }
+    // norm statistics: every thread summed its own channels over all of the block's tiles; one reduction per block,
+    // one partial row per persistent block (row = blockIdx.x, gridDim.x rows in all)
+    if (!SC && a.stats) {
+        float* red = (float*)smem;
+        __syncthreads();
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float u = s1[n][r], v = s2[n][r];
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[n][r], v = s2[n][r];
 #pragma unroll
-                    for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
-                    if (j == 0) {
-                        int cl = n * 16 + gq * 4 + r;
-                        red[(wave * NT * 16 + cl) * 2 + 0] = u;
-                        red[(wave * NT * 16 + cl) * 2 + 1] = v;
-                    }
+                for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+                if (j == 0) {
+                    int cl = n * 16 + gq * 4 + r;
+                    red[(wave * NT * 16 + cl) * 2 + 0] = u;
+                    red[(wave * NT * 16 + cl) * 2 + 1] = v;
                 }
-            __syncthreads();
-            if (tid < NT * 16) {
-                float u = 0.f, v = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
-                int c = nt0 * 16 + tid;
-                a.stats[((size_t)bid * g.Cout + c) * 2 + 0] = u;
-                a.stats[((size_t)bid * g.Cout + c) * 2 + 1] = v;
             }
+        __syncthreads();
+        if (tid < NT * 16) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
+            int c = nt0 * 16 + tid;
+            a.stats[((size_t)blockIdx.x * g.Cout + c) * 2 + 0] = u;
+            a.stats[((size_t)blockIdx.x * g.Cout + c) * 2 + 1] = v;
         }
     }
 }
 
 // ---- launch plumbing ----
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
-static void launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
+static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns gridDim.x = the number of statistics partial rows
     constexpr int NW = (BZ * BY * BX / 16) % 8 == 0 && BZ * BY * BX >= 256 ? 8 : 4;   // waves per block
     MfmaConvArgs a = a0;
     a.tiles_x = (a.g.Wo + BX - 1) / BX; a.tiles_y = (a.g.Ho + BY - 1) / BY; a.tiles_z = (a.g.Do + BZ - 1) / BZ;
@@ -591,11 +594,12 @@ static void launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {
     if (gx > tiles) gx = tiles;
     dim3 grid((unsigned)gx, (unsigned)gy);
     k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW><<<grid, NW * 64, lds, s>>>(a);
+    return gx;
 }
-template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> static void launch_nt(const MfmaConvArgs& a, hipStream_t s) {
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> static int launch_nt(const MfmaConvArgs& a, hipStream_t s) {
     int ntt = a.g.Cout / 16;
     if constexpr (SC) {   // scatter kinds always have ntt % 4 == 0 (rows = 8 * C, C % 16 == 0)
-        launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, true>(a, s);
+        return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, true>(a, s);
     } else {
         // row tiles per block: as many as divide the row count, fewer when the grid would not fill the 256 CUs
         int tiles = ((a.g.Wo + BX - 1) / BX) * ((a.g.Ho + BY - 1) / BY) * ((a.g.Do + BZ - 1) / BZ);
@@ -603,9 +607,9 @@ template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> stati
         constexpr int T = KD * KD * KD, KSTEPS = CK == 32 ? T : (T + 1) / 2;
         while (nt > 1 && KSTEPS * nt > 32) nt >>= 1;            // keep the chunk's filter fragments LDS-resident
         while (nt > 1 && (int64_t)tiles * (ntt / nt) < 256) nt >>= 1;
-        if (nt == 4) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
-        else if (nt == 2) launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
-        else launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, false>(a, s);
+        if (nt == 4) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
+        if (nt == 2) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
+        return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, false>(a, s);
     }
 }
 
@@ -618,19 +622,19 @@ static Tile tile_s1k3(const ConvGeom& g, int CK) {
     if ((int64_t)tile_count(g, big) * (g.Cout / 16) >= 256) return big;
     return g.Wo >= 12 ? Tile{2, 4, 16} : (g.Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4});
 }
-static void launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
+static int launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
     Tile t = tile_s1k3(a.g, CK);
-    if (t.bx == 16 && t.bz == 4) { if (CK == 32) launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }
-    else if (t.bx == 16) { if (CK == 32) launch_nt<1, 3, 1, 2, 4, 16, 32, false>(a, s); else launch_nt<1, 3, 1, 2, 4, 16, 16, false>(a, s); }
-    else if (t.bx == 8 && t.bz == 4) { if (CK == 32) launch_nt<1, 3, 1, 4, 8, 8, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 8, 8, 16, false>(a, s); }
-    else if (t.bx == 8) { if (CK == 32) launch_nt<1, 3, 1, 2, 4, 8, 32, false>(a, s); else launch_nt<1, 3, 1, 2, 4, 8, 16, false>(a, s); }
-    else { if (CK == 32) launch_nt<1, 3, 1, 4, 4, 4, 32, false>(a, s); else launch_nt<1, 3, 1, 4, 4, 4, 16, false>(a, s); }
+    if (t.bx == 16 && t.bz == 4) { if (CK == 32) return launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }
+    else if (t.bx == 16) { if (CK == 32) return launch_nt<1, 3, 1, 2, 4, 16, 32, false>(a, s); else return launch_nt<1, 3, 1, 2, 4, 16, 16, false>(a, s); }
+    else if (t.bx == 8 && t.bz == 4) { if (CK == 32) return launch_nt<1, 3, 1, 4, 8, 8, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 8, 8, 16, false>(a, s); }
+    else if (t.bx == 8) { if (CK == 32) return launch_nt<1, 3, 1, 2, 4, 8, 32, false>(a, s); else return launch_nt<1, 3, 1, 2, 4, 8, 16, false>(a, s); }
+    else { if (CK == 32) return launch_nt<1, 3, 1, 4, 4, 4, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 4, 4, 16, false>(a, s); }
 }
 static Tile tile_s2k3(int Wo) { return Wo >= 12 ? Tile{2, 4, 16} : (Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4}); }
-static void launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 only (halo of a stride-2 tile is 8x the output tile)
-    if (a.g.Wo >= 12) launch_nt<2, 3, 1, 2, 4, 16, 16, false>(a, s);
-    else if (a.g.Wo > 4) launch_nt<2, 3, 1, 2, 4, 8, 16, false>(a, s);
-    else launch_nt<2, 3, 1, 4, 4, 4, 16, false>(a, s);
+static int launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 only (halo of a stride-2 tile is 8x the output tile)
+    if (a.g.Wo >= 12) return launch_nt<2, 3, 1, 2, 4, 16, 16, false>(a, s);
+    else if (a.g.Wo > 4) return launch_nt<2, 3, 1, 2, 4, 8, 16, false>(a, s);
+    else return launch_nt<2, 3, 1, 4, 4, 4, 16, false>(a, s);
 }
 static void launch_s2k2(const MfmaConvArgs& a, hipStream_t s) {   // conv_trans dgrad, CK 16
     if (a.g.Wo >= 12) launch_nt<2, 2, 0, 2, 4, 16, 16, false>(a, s);
@@ -703,15 +707,15 @@ int mfma_conv_blocks(const ConvGeom& g) {
     Tile t = g.stride == 1 ? tile_s1k3(g, fwd_ck(g)) : tile_s2k3(g.Wo);
     return tile_count(g, t);
 }
-void launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
-                          float* stats_partial, hipStream_t s) {
+int launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
+                         float* stats_partial, hipStream_t s) {
     MfmaConvArgs a = base_args();
     a.g = g; a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
     a.w = w_mfma; a.bias = bias;
     a.out[0] = out; a.outC[0] = g.Cout;
     a.stats = stats_partial;
     a.oD = g.Do; a.oH = g.Ho; a.oW = g.Wo;
-    if (g.stride == 1) launch_s1k3(a, fwd_ck(g), s); else launch_s2k3(a, s);
+    return g.stride == 1 ? launch_s1k3(a, fwd_ck(g), s) : launch_s2k3(a, s);
 }
 // dgrad (g = forward geometry).  stride 1: 27-tap conv of dL/dy with the flipped filter.  stride 2: 8-tap conv of
 // dL/dy on the coarse grid producing all 8 output parities at once (rows = 8*Cin), scattered to 2*m + parity.
