@@ -38,179 +38,6 @@ struct MfmaConvArgs {
     int oD, oH, oW;      // destination volume
 };
 
-template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
-__global__ void __launch_bounds__(256) k_mfma_conv(MfmaConvArgs a) {
-    constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD, NVOX = HZ * HY * HX;
-    constexpr int G = CK / 8;                    // 16-B channel groups per voxel
-    constexpr int VS = CK == 32 ? 96 : 32;       // LDS bytes per voxel (96: conflict-free ds_read_b128 for 64-B payloads)
-    constexpr int TXM = BX < 16 ? BX : 16;       // m-tile = TYM rows x TXM columns of one z-plane
-    constexpr int TYM = 16 / TXM;
-    constexpr int MT = BZ * BY * BX / 16, MTW = MT / 4;
-    constexpr int T = KD * KD * KD;
-    constexpr int KSTEPS = CK == 32 ? T : (T + 1) / 2;
-    static_assert(MT % 4 == 0 && MTW >= 1, "tile must give every wave at least one m-tile");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const ConvGeom& g = a.g;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
-    const int nblk = a.tiles_x * a.tiles_y * a.tiles_z;
-    const int bid = xcd_remap(blockIdx.x, nblk);
-    const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
-    const int nt0 = blockIdx.y * NT, NTT = g.Cout / 16;
-
-    // this lane's voxel of each of the wave's m-tiles: tile-local coordinates and LDS byte offset
-    int mz[MTW], my[MTW], mx[MTW], mbase[MTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        int mt = wave * MTW + i;
-        constexpr int RG = BY / TYM;             // row groups per z-plane
-        mz[i] = mt / RG; my[i] = (mt % RG) * TYM + (j / TXM); mx[i] = j % TXM;
-        mbase[i] = ((mz[i] * S * HY + my[i] * S) * HX + mx[i] * S) * VS + (CK == 32 ? gq : (gq & 1)) * 16;
-    }
-
-    f32x4 acc[MTW][NT];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int C0 = a.src[0].C;
-    const int lg = tid % G;                      // this thread's channel group inside the chunk (256 % G == 0)
-    const int nchunk = g.Cin / CK;
-    const bf16x8* wp = (const bf16x8*)a.w;
-    const int iz0 = z0 * S - PAD, iy0 = y0 * S - PAD, ix0 = x0 * S - PAD;
-
-    for (int q = 0; q < nchunk; ++q) {
-        // ---- stage the halo tile of channels [q*CK, q*CK+CK) ----
-        {
-            int c = q * CK + lg * 8;
-            int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
-            const SrcDesc& sd = a.src[s];
-            int cl = c - (s ? C0 : 0);
-            const char* base = (const char*)sd.ptr + (size_t)cl * 2;
-            float sc[8], sh[8];
-            const bool xf = sd.scale != nullptr;
-            if (xf) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { sc[e] = sd.scale[cl + e]; sh[e] = sd.shift[cl + e]; }
-            }
-            const int act = sd.act;
-            constexpr int UNITS = NVOX * G, ITERS = (UNITS + 255) / 256;
-            __syncthreads();                      // previous chunk's reads are done
-#pragma unroll 4
-            for (int it = 0; it < ITERS; ++it) {
-                int u = tid + it * 256;
-                if (u < UNITS) {
-                    int hv = u / G;
-                    int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
-                    int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
-                        size_t vox = ((size_t)gz * g.H + gy) * g.W + gx;
-                        v = transform8(*(const uint4*)(base + vox * (size_t)sd.C * 2), xf, sc, sh, act);
-                    }
-                    *(uint4*)(smem + hv * VS + lg * 16) = v;
-                }
-            }
-            __syncthreads();
-        }
-        // ---- taps x MFMA ----
-        const bf16x8* wq = wp + ((size_t)q * KSTEPS * NTT + nt0) * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            bf16x8 wf[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n) wf[n] = wq[((size_t)ks * NTT + n) * 64];
-            int toff;
-            if (CK == 32) {
-                toff = (((ks / (KD * KD)) * HY + (ks / KD) % KD) * HX + ks % KD) * VS;
-            } else {
-                const int t0 = 2 * ks, t1 = 2 * ks + 1 < T ? 2 * ks + 1 : 2 * ks;   // a tap past the last one has a zero filter
-                const int o0 = (((t0 / (KD * KD)) * HY + (t0 / KD) % KD) * HX + t0 % KD) * VS;
-                const int o1 = (((t1 / (KD * KD)) * HY + (t1 / KD) % KD) * HX + t1 % KD) * VS;
-                toff = (lane & 32) ? o1 : o0;
-            }
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                bf16x8 xb = *(const bf16x8*)(smem + mbase[i] + toff);
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xb, acc[i][n], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- epilogue ----
-    float s1[NT][4], s2[NT][4];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        int c = (nt0 + n) * 16 + gq * 4;          // first of this lane's 4 rows
-        int tz = 0, ty = 0, tx = 0;
-        if (SC) { int tap = c / a.sc_C; c -= tap * a.sc_C; tz = tap >> 2; ty = (tap >> 1) & 1; tx = tap & 1; }
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) b4[r] = a.bias[c + r];
-        }
-        int d = (a.nout > 1 && c >= a.outC[0]) ? 1 : 0;
-        int cd = c - (d ? a.outC[0] : 0);
-        char* obase = (char*)a.out[d];
-        const int oC = a.outC[d], oacc = a.out_acc[d];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            int gz = z0 + mz[i], gy = y0 + my[i], gx = x0 + mx[i];
-            if (SC) { gz = 2 * gz + tz; gy = 2 * gy + ty; gx = 2 * gx + tx; }
-            if (gz < a.oD && gy < a.oH && gx < a.oW && obase) {
-                size_t vox = ((size_t)gz * a.oH + gy) * a.oW + gx;
-                uint2* p = (uint2*)(obase + (vox * oC + cd) * 2);
-                float v0 = acc[i][n][0] + b4[0], v1 = acc[i][n][1] + b4[1], v2 = acc[i][n][2] + b4[2], v3 = acc[i][n][3] + b4[3];
-                if (oacc) {
-                    uint2 old = *p;
-                    v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
-                }
-                uint2 o;
-                o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
-                *p = o;
-                if (!SC && a.stats) {   // statistics of the values as stored (rounded to bf16)
-                    float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
-                    s1[n][0] += r0; s1[n][1] += r1; s1[n][2] += r2; s1[n][3] += r3;
-                    s2[n][0] = fmaf(r0, r0, s2[n][0]); s2[n][1] = fmaf(r1, r1, s2[n][1]);
-                    s2[n][2] = fmaf(r2, r2, s2[n][2]); s2[n][3] = fmaf(r3, r3, s2[n][3]);
-                }
-            }
-        }
-    }
-    if (!SC && a.stats) {
-        float* red = (float*)smem;                // [wave][NT*16][2]
-        __syncthreads();                          // LDS tile no longer needed
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float u = s1[n][r], v = s2[n][r];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
-                if (j == 0) {
-                    int cl = n * 16 + gq * 4 + r;
-                    red[(wave * NT * 16 + cl) * 2 + 0] = u;
-                    red[(wave * NT * 16 + cl) * 2 + 1] = v;
-                }
-            }
-        __syncthreads();
-        if (tid < NT * 16) {
-            float u = 0.f, v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
-            int c = nt0 * 16 + tid;
-            a.stats[((size_t)bid * g.Cout + c) * 2 + 0] = u;
-            a.stats[((size_t)bid * g.Cout + c) * 2 + 1] = v;
-        }
-    }
-}
-
 // ---- filter packing: fp32 torch layout -> bf16 fragments [chunk][kstep][row tile][lane][8] ----
 enum PackMode {
     PK_CONV_FWD = 0,    // rows o = cout, k-channel i = cin, T taps:           w[(o*A + i)*T + t]              A = Cin
@@ -324,7 +151,6 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
     constexpr int TILE_B = HZ * HY * HXP * VS;
     constexpr int WPIECES = KSTEPS * NT * 64, WITERS = WLDS ? (WPIECES + NTHR - 1) / NTHR : 1;
     static_assert(MT % NW == 0 && MTW >= 1, "tile must give every wave at least one m-tile");
-    static_assert(ITERS <= 32, "in-bounds mask is one 32-bit word");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const ConvGeom& g = a.g;
@@ -365,16 +191,23 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
     // Per-thread staging units, decoded ONCE: halo coordinates (packed 10 bits each, -1 = no unit) and LDS byte offset.
     // (PMC on the first version: 39 % of wave cycles issuing instructions, almost all of it this index arithmetic
     // repeated per unit per tile: constant divisions, 64-bit address math, swizzle.)
+    // uvox = the unit's voxel index relative to the halo origin in the SOURCE volume: a load address is
+    // base(tile, chunk) + uvox * voxel stride, one 24-bit multiply-add per unit (the 64-bit (z*H+y)*W+x chains of the
+    // previous version were ~100 quarter-rate VALU instructions per tile and wave -- 6 VALU per MFMA, PMC SQ_INSTS_VALU).
     int ucoord[ITERS], ulds[ITERS];
+    unsigned uvox[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int u = tid + it * NTHR;
         const int hv = u / G, hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
         ucoord[it] = u < UNITS ? (hz | (hy << 10) | (hx << 20)) : -1;
         ulds[it] = SWZ ? ((hz * HY + hy) * HXP + hx) * 64 + ((lg ^ (((hx >> 2) & 1) << 1)) << 4) : hv * VS + lg * 16;
+        uvox[it] = (unsigned)((hz * g.H + hy) * g.W + hx);
     }
+    unsigned mvox[MTW];             // same for the outputs of this lane's m-tiles (non-scatter kinds)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) mvox[i] = (unsigned)((mz[i] * a.oH + my[i]) * a.oW + mx[i]);
     uint4 R[ITERS], RW[WITERS];
-    unsigned inb = 0;
     // issue the global loads of stage st into R (no waiting)
     auto prefetch = [&](int st) {
         const int k = st / nchunk, q = st - k * nchunk;
@@ -394,21 +227,26 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
         const int c = q * CK + lg * 8;
         const int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
         const SrcDesc& sd = a.src[s];
-        const char* base = (const char*)sd.ptr + (size_t)(c - (s ? C0 : 0)) * 2;
-        inb = 0;
-        const size_t vstride = (size_t)sd.C * 2;
+        const long long org = ((long long)iz0 * g.H + iy0) * g.W + ix0;          // halo origin (may lie outside the volume)
+        const char* base = (const char*)sd.ptr + (org * sd.C + (c - (s ? C0 : 0))) * 2;
+        const unsigned vstride = (unsigned)sd.C * 2;
+        const bool interior = iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + HZ <= g.D && iy0 + HY <= g.H && ix0 + HX <= g.W;
+        if (interior) {
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int uc = ucoord[it];
-            const int gz = iz0 + (uc & 1023), gy = iy0 + ((uc >> 10) & 1023), gx = ix0 + (uc >> 20);
-            R[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (uc >= 0 && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W) {
-                R[it] = *(const uint4*)(base + (((size_t)gz * g.H + gy) * g.W + gx) * vstride);
-                inb |= 1u << it;
+            for (int it = 0; it < ITERS; ++it)
+                if (ucoord[it] >= 0) R[it] = *(const uint4*)(base + __umul24(uvox[it], vstride));
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int uc = ucoord[it];
+                const int gz = iz0 + (uc & 1023), gy = iy0 + ((uc >> 10) & 1023), gx = ix0 + (uc >> 20);
+                R[it] = make_uint4(0u, 0u, 0u, 0u);
+                if (uc >= 0 && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
+                    R[it] = *(const uint4*)(base + __umul24(uvox[it], vstride));
             }
         }
     };
-    // transform (if the source carries one) and write R to the LDS tile
+    // write R to the LDS tile (sources are plain: a tensor with a pending norm/activation is read through its activated copy)
     auto commit = [&](int st) {
         const int k = st / nchunk, q = st - k * nchunk;
         if (WLDS && (nchunk > 1 || st == 0)) {
@@ -418,25 +256,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
                 if (pc < WPIECES) *(uint4*)(smem + TILE_B + pc * 16) = RW[it];
             }
         }
-        const int c = q * CK + lg * 8;
-        const int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
-        const SrcDesc& sd = a.src[s];
-        const int cl = c - (s ? C0 : 0);
-        const bool xf = sd.scale != nullptr;
-        const int act = sd.act;
-        float sc[8], sh[8];
-        if (xf) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[e] = sd.scale[cl + e]; sh[e] = sd.shift[cl + e]; }
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            if (ucoord[it] >= 0) {
-                uint4 v = R[it];
-                if ((xf || act) && ((inb >> it) & 1u)) v = transform8(v, xf, sc, sh, act);
-                *(uint4*)(smem + ulds[it]) = v;
-            }
-        }
+        for (int it = 0; it < ITERS; ++it)
+            if (ucoord[it] >= 0) *(uint4*)(smem + ulds[it]) = R[it];
     };
 
     float s1[NT][4], s2[NT][4];      // per-thread norm statistics of the stored outputs (channels nt0*16 + n*16 + gq*4 + r)
@@ -509,13 +331,17 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
             int cd = c - (d ? a.outC[0] : 0);
             char* obase = (char*)a.out[d];
             const int oC = a.outC[d], oacc = a.out_acc[d];
+            // non-scatter kinds: address = tile origin (uniform) + this lane's precomputed voxel offset
+            const bool edge = z0 + BZ > a.oD || y0 + BY > a.oH || x0 + BX > a.oW;
+            char* tbase = obase + ((((long long)z0 * a.oH + y0) * a.oW + x0) * oC + cd) * 2;
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
                 int gz = z0 + mz[i], gy = y0 + my[i], gx = x0 + mx[i];
                 if (SC) { gz = 2 * gz + tz; gy = 2 * gy + ty; gx = 2 * gx + tx; }
-                if (gz < a.oD && gy < a.oH && gx < a.oW && obase) {
-                    size_t vox = ((size_t)gz * a.oH + gy) * a.oW + gx;
-                    uint2* p = (uint2*)(obase + (vox * oC + cd) * 2);
+                if (((!SC && !edge) || (gz < a.oD && gy < a.oH && gx < a.oW)) && obase) {
+                    uint2* p;
+                    if (SC) p = (uint2*)(obase + ((((size_t)gz * a.oH + gy) * a.oW + gx) * oC + cd) * 2);
+                    else p = (uint2*)(tbase + __umul24(mvox[i], (unsigned)oC * 2));
                     float v0 = acc[i][n][0] + b4[0], v1 = acc[i][n][1] + b4[1], v2 = acc[i][n][2] + b4[2], v3 = acc[i][n][3] + b4[3];
                     if (oacc) {
                         uint2 old = *p;
@@ -655,7 +481,7 @@ static void launch_k2sc(const MfmaConvArgs& a, hipStream_t s) {   // conv s2 dgr
 static bool chan_ok(const ConvGeom& g, const SrcDesc* src, int nsrc) {
     if (g.Cin % 16 || g.Cout % 16) return false;
     for (int s = 0; s < nsrc; ++s)
-        if (src[s].C % 16) return false;
+        if (src[s].C % 16 || src[s].scale || src[s].act) return false;   // plain sources only (engine: activated copies)
     return true;
 }
 static MfmaConvArgs base_args() {
