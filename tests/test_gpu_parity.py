@@ -64,6 +64,8 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     # register-accumulating small wgrads: first conv (Cin = 1; W % 4 != 0 falls back to the row kernel) and 1x1x1 heads
     (1, 8, (6, 5, 8), 3, 1), (1, 16, (5, 6, 7), 3, 1), (1, 32, (17, 9, 16), 3, 1), (64, 6, (4, 5, 6), 1, 1), (256, 6, (3, 4, 5), 1, 1),
     (32, 3, (5, 6, 7), 1, 1), (16, 8, (33, 8, 9), 1, 1),
+    # small-volume MFMA kernel: 8 chunks (two per wave, fragment refill), 16 chunks (two super-stages), 4^3 tile
+    (256, 16, (8, 8, 8), 3, 1), (512, 32, (5, 6, 7), 3, 1), (256, 32, (4, 4, 4), 3, 1), (96, 32, (3, 4, 10), 3, 1),
 ]
 
 

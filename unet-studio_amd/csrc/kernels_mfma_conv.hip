@@ -391,6 +391,188 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small volumes (the 16^3 / 8^3 / 4^3 levels of the default architecture: 3 % of the FLOPs but 15 % of the step in the
+// persistent kernel).  With 64..512 blocks of tiny tiles every pipeline stage of k_mfma_conv_p is one exposed latency:
+// (global load -> LDS -> barrier -> 27 LDS-latency-bound taps) x Cin/32 chunks, ~6 us per chunk at one wave per SIMD.
+// Here a block (4 waves) owns a 64-voxel tile x 16 output rows and
+//   1. stages the halo tile of up to SMALL_QS = 8 channel chunks (256 channels, <= 147 KB) in ONE burst of loads,
+//   2. splits the chunks over its waves (wave w: chunks w, w+4): every wave runs all 4 m-tiles of the tile over its share
+//      of K with the chunk's 27 filter fragments held in registers (loaded straight from L2 in lane order, refilled for
+//      the wave's next chunk as the taps retire them), so the tap loop waits on LDS only,
+//   3. sums the 4 partial accumulators through LDS; wave w finishes m-tile w (bias, bf16, statistics, accumulate).
+// Same LDS tile layout (64-B voxels, swizzled), filter pack, arguments and epilogue semantics as k_mfma_conv_p<1,3,1,..,32,1,false>.
+// ------------------------------------------------------------------------------------------------
+constexpr int SMALL_QS = 8;
+template <int BZ, int BY, int BX, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
+    constexpr int HZ = BZ + 2, HY = BY + 2, HX = BX + 2, HXP = (HX + 3) / 4 * 4;
+    constexpr int TXM = BX < 16 ? BX : 16, TYM = 16 / TXM, RG = BY / TYM;
+    constexpr int TILE_B = HZ * HY * HXP * 64;
+    constexpr int UNITS = HZ * HY * HX * 4, ITERS = (UNITS + 255) / 256;
+    constexpr int QB = OCC == 1 ? 4 : 2;   // chunks per staging burst (registers: QB * ITERS * 4)
+    static_assert(BZ * BY * BX == 64, "four m-tiles per tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4, lg = tid & 3;
+    const int nt0 = blockIdx.y, NTT = g.Cout / 16, nchunk = g.Cin / 32, C0 = a.src[0].C;
+    const int bid = blockIdx.x;
+    const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
+    const int iz0 = z0 - 1, iy0 = y0 - 1, ix0 = x0 - 1;
+    const bf16x8* wp = (const bf16x8*)a.w;
+
+    int mbase[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mz = i / RG, my = (i % RG) * TYM + j / TXM, mx = j % TXM;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hx = mx + kx;
+            mbase[i][kx] = ((mz * HY + my) * HXP + hx) * 64 + ((gq ^ (((hx >> 2) & 1) << 1)) << 4);
+        }
+    }
+    int ulds[ITERS];
+    unsigned uvox[ITERS], uin = 0;            // uin bit it: the unit exists and lies inside the volume
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int u = tid + it * 256;
+        const int hv = u >> 2, hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
+        ulds[it] = u < UNITS ? ((hz * HY + hy) * HXP + hx) * 64 + ((lg ^ (((hx >> 2) & 1) << 1)) << 4) : -1;
+        uvox[it] = (unsigned)((hz * g.H + hy) * g.W + hx);
+        const int gz = iz0 + hz, gy = iy0 + hy, gx = ix0 + hx;
+        if (u < UNITS && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W) uin |= 1u << it;
+    }
+    const long long org = ((long long)iz0 * g.H + iy0) * g.W + ix0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int q0 = 0; q0 < nchunk; q0 += SMALL_QS) {
+        const int nq = nchunk - q0 < SMALL_QS ? nchunk - q0 : SMALL_QS;
+        // this wave's first chunk of the super-stage: its 27 filter fragments, in flight during the staging below
+        bf16x8 wf[27];
+        {
+            const int qq = wave < nq ? wave : 0;
+            const bf16x8* wq = wp + ((size_t)(q0 + qq) * 27 * NTT + nt0) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 27; ++ks) wf[ks] = wq[(size_t)ks * NTT * 64];
+        }
+        __syncthreads();                 // the previous super-stage's tiles are no longer read
+#pragma unroll 1
+        for (int qb = 0; qb < nq; qb += QB) {
+            uint4 R[QB][ITERS];
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+                if (qb + qq < nq) {
+                    const int c = (q0 + qb + qq) * 32 + lg * 8;
+                    const int sidx = (a.nsrc > 1 && c >= C0) ? 1 : 0;
+                    const SrcDesc& sd = a.src[sidx];
+                    const char* base = (const char*)sd.ptr + (org * sd.C + (c - (sidx ? C0 : 0))) * 2;
+                    const unsigned vstride = (unsigned)sd.C * 2;
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        R[qq][it] = make_uint4(0u, 0u, 0u, 0u);
+                        if ((uin >> it) & 1u) R[qq][it] = *(const uint4*)(base + __umul24(uvox[it], vstride));
+                    }
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < QB; ++qq) {
+                if (qb + qq < nq) {
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it)
+                        if (ulds[it] >= 0) *(uint4*)(smem + (qb + qq) * TILE_B + ulds[it]) = R[qq][it];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int qq = wave; qq < nq; qq += 4) {
+            const char* tile = smem + qq * TILE_B;
+            const bool more = OCC == 1 && qq + 4 < nq;   // OCC 2 is launched with nq <= 4 only: one chunk per wave
+            const bf16x8* wn = wp + ((size_t)(q0 + qq + 4) * 27 * NTT + nt0) * 64 + lane;   // the wave's next chunk (if more)
+            bf16x8 xbuf[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xbuf[0][i] = *(const bf16x8*)(tile + mbase[i][0]);
+#pragma unroll
+            for (int ks = 0; ks < 27; ++ks) {
+                if (ks + 1 < 27) {
+                    const int k1 = ks + 1, toff = ((k1 / 9) * HY + (k1 / 3) % 3) * HXP * 64;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xbuf[k1 & 1][i] = *(const bf16x8*)(tile + mbase[i][k1 % 3] + toff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xbuf[ks & 1][i], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) wf[ks] = wn[(size_t)ks * NTT * 64];
+            }
+        }
+    }
+
+    // ---- sum the four K-partials; wave w finishes m-tile w ----
+    __syncthreads();
+    float* red = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4*)(red + ((wave * 4 + i) * 64 + lane) * 4) = acc[i];
+    __syncthreads();
+    f32x4 o4 = *(const f32x4*)(red + ((0 * 4 + wave) * 64 + lane) * 4);
+#pragma unroll
+    for (int v = 1; v < 4; ++v) {
+        const f32x4 t = *(const f32x4*)(red + ((v * 4 + wave) * 64 + lane) * 4);
+        o4[0] += t[0]; o4[1] += t[1]; o4[2] += t[2]; o4[3] += t[3];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int c = nt0 * 16 + gq * 4;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = a.bias[c + r];
+        }
+        const int d = (a.nout > 1 && c >= a.outC[0]) ? 1 : 0;
+        const int cd = c - (d ? a.outC[0] : 0);
+        char* obase = (char*)a.out[d];
+        const int oC = a.outC[d], oacc = a.out_acc[d];
+        const int mz = wave / RG, my = (wave % RG) * TYM + j / TXM, mx = j % TXM;
+        const int gz = z0 + mz, gy = y0 + my, gx = x0 + mx;
+        if (gz < a.oD && gy < a.oH && gx < a.oW && obase) {
+            const size_t vox = ((size_t)gz * a.oH + gy) * a.oW + gx;
+            uint2* p = (uint2*)(obase + (vox * oC + cd) * 2);
+            float v0 = o4[0] + b4[0], v1 = o4[1] + b4[1], v2 = o4[2] + b4[2], v3 = o4[3] + b4[3];
+            if (oacc) {
+                const uint2 old = *p;
+                v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+            *p = o;
+            const float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
+            s1[0] = r0; s1[1] = r1; s1[2] = r2; s1[3] = r3;
+            s2[0] = r0 * r0; s2[1] = r1 * r1; s2[2] = r2 * r2; s2[3] = r3 * r3;
+        }
+    }
+    if (a.stats) {   // statistics of the values as stored: one partial row per tile
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float u = s1[r], v = s2[r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+            if (j == 0) { red[(wave * 16 + gq * 4 + r) * 2] = u; red[(wave * 16 + gq * 4 + r) * 2 + 1] = v; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { u += red[(w * 16 + tid) * 2]; v += red[(w * 16 + tid) * 2 + 1]; }
+            a.stats[((size_t)bid * g.Cout + nt0 * 16 + tid) * 2 + 0] = u;
+            a.stats[((size_t)bid * g.Cout + nt0 * 16 + tid) * 2 + 1] = v;
+        }
+    }
+}
+
 // ---- launch plumbing ----
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
 static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns gridDim.x = the number of statistics partial rows
@@ -443,13 +625,38 @@ template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> stati
 struct Tile { int bz, by, bx; };
 static int tile_count(const ConvGeom& g, Tile t) { return ((g.Wo + t.bx - 1) / t.bx) * ((g.Ho + t.by - 1) / t.by) * ((g.Do + t.bz - 1) / t.bz); }
 // small volumes (the deep levels) get small tiles so that tiles x row-tiles still covers the chip
+static bool small_s1k3(const ConvGeom& g, int CK) {   // few big tiles: the volume is small, use k_mfma_conv_small (CK 32)
+    Tile big = g.Wo >= 12 ? (CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16}) : (g.Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4});
+    return (int64_t)tile_count(g, big) * (g.Cout / 16) < 256;
+}
 static Tile tile_s1k3(const ConvGeom& g, int CK) {
     Tile big = g.Wo >= 12 ? (CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16}) : (g.Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4});
-    if ((int64_t)tile_count(g, big) * (g.Cout / 16) >= 256) return big;
+    if (!small_s1k3(g, CK)) return big;
+    if (CK == 32) return g.Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4};
     return g.Wo >= 12 ? Tile{2, 4, 16} : (g.Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4});
+}
+template <int BZ, int BY, int BX> static int launch_small(const MfmaConvArgs& a0, hipStream_t s) {
+    MfmaConvArgs a = a0;
+    a.tiles_x = (a.g.Wo + BX - 1) / BX; a.tiles_y = (a.g.Ho + BY - 1) / BY; a.tiles_z = (a.g.Do + BZ - 1) / BZ;
+    constexpr size_t tile_b = (size_t)(BZ + 2) * (BY + 2) * ((BX + 2 + 3) / 4 * 4) * 64;
+    static_assert(SMALL_QS * tile_b <= 160 * 1024 && tile_b >= 16 * 1024, "LDS budget / reduction scratch");
+    const int nchunk = a.g.Cin / 32, nq = nchunk < SMALL_QS ? nchunk : SMALL_QS;
+    const size_t lds = (size_t)nq * tile_b;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_mfma_conv_small<BZ, BY, BX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMALL_QS * tile_b));
+        (void)hipFuncSetAttribute((const void*)k_mfma_conv_small<BZ, BY, BX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_done = true;
+    }
+    const int tiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    dim3 grid((unsigned)tiles, (unsigned)(a.g.Cout / 16));
+    if (lds <= 80 * 1024) k_mfma_conv_small<BZ, BY, BX, 2><<<grid, 256, lds, s>>>(a);   // two blocks per CU
+    else k_mfma_conv_small<BZ, BY, BX, 1><<<grid, 256, lds, s>>>(a);
+    return tiles;
 }
 static int launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
     Tile t = tile_s1k3(a.g, CK);
+    if (CK == 32 && small_s1k3(a.g, CK)) return t.bx == 8 ? launch_small<2, 4, 8>(a, s) : launch_small<4, 4, 4>(a, s);
     if (t.bx == 16 && t.bz == 4) { if (CK == 32) return launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }
     else if (t.bx == 16) { if (CK == 32) return launch_nt<1, 3, 1, 2, 4, 16, 32, false>(a, s); else return launch_nt<1, 3, 1, 2, 4, 16, 16, false>(a, s); }
     else if (t.bx == 8 && t.bz == 4) { if (CK == 32) return launch_nt<1, 3, 1, 4, 8, 8, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 8, 8, 16, false>(a, s); }
