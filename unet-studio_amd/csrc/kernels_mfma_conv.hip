@@ -125,7 +125,10 @@ static void run_pack(const float* w, void* out, int Ci, int Co, int CK, int T, i
 // latency hides under the matrix work even at 2 blocks per CU (measured: the one-shot kernel spent ~6 % of
 // a block's lifetime in MFMAs, the rest waiting for the halo tile).
 // ------------------------------------------------------------------------------------------------
-template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC, int NW>
+// ONE: Cin == CK is known at compile time (the two heaviest layers, 32->16 and 16->16 at 128^3): the filter fragments are
+// staged once before the loop instead of riding in prefetch registers through every stage (those 16 VGPRs made the
+// 128-VGPR variants spill their prefetched halo data), and the stage -> (tile, chunk) divisions disappear.
+template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC, int NW, bool ONE>
 // launch bounds: 2 resident blocks per CU (4 waves/SIMD, <= 128 VGPRs) for the 8-wave light configurations, else 2 waves/SIMD (<= 256)
 __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_conv_p(MfmaConvArgs a) {
     constexpr int NTHR = NW * 64;   // 8 waves on the larger tiles: half the staging registers per thread, 4 waves per SIMD at 2 blocks/CU
@@ -159,23 +162,25 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
     const int nt0 = blockIdx.y * NT, NTT = g.Cout / 16;
     const int C0 = a.src[0].C;
     const int lg = tid % G;
-    const int nchunk = g.Cin / CK;
+    const int nchunk = ONE ? 1 : g.Cin / CK;
     const bf16x8* wp = (const bf16x8*)a.w;
 
-    int mz[MTW], my[MTW], mx[MTW], mbase[MTW][NKX];
+    int mbase[MTW][NKX];
+    unsigned mvox[MTW];                 // this lane's voxel of m-tile i: offset from the tile origin in the destination volume (non-scatter kinds)
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         int mt = wave * MTW + i;
         constexpr int RG = BY / TYM;
-        mz[i] = mt / RG; my[i] = (mt % RG) * TYM + (j / TXM); mx[i] = j % TXM;
+        const int mz = mt / RG, my = (mt % RG) * TYM + (j / TXM), mx = j % TXM;
+        mvox[i] = (unsigned)((mz * a.oH + my) * a.oW + mx);
         if (SWZ) {
 #pragma unroll
             for (int kx = 0; kx < NKX; ++kx) {
-                const int hx = mx[i] + kx;
-                mbase[i][kx] = ((mz[i] * HY + my[i]) * HXP + hx) * 64 + ((gq ^ (((hx >> 2) & 1) << 1)) << 4);
+                const int hx = mx + kx;
+                mbase[i][kx] = ((mz * HY + my) * HXP + hx) * 64 + ((gq ^ (((hx >> 2) & 1) << 1)) << 4);
             }
         } else {
-            mbase[i][0] = ((mz[i] * S * HY + my[i] * S) * HX + mx[i] * S) * VS + (CK == 32 ? gq : (gq & 1)) * 16;
+            mbase[i][0] = ((mz * S * HY + my * S) * HX + mx * S) * VS + (CK == 32 ? gq : (gq & 1)) * 16;
         }
     }
     f32x4 acc[MTW][NT];
@@ -194,30 +199,38 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
     // uvox = the unit's voxel index relative to the halo origin in the SOURCE volume: a load address is
     // base(tile, chunk) + uvox * voxel stride, one 24-bit multiply-add per unit (the 64-bit (z*H+y)*W+x chains of the
     // previous version were ~100 quarter-rate VALU instructions per tile and wave -- 6 VALU per MFMA, PMC SQ_INSTS_VALU).
-    int ucoord[ITERS], ulds[ITERS];
-    unsigned uvox[ITERS];
+    // upk = halo coordinates (z 4 bits | y 5 bits << 4 | x 6 bits << 9) | LDS offset / 16 << 15, or -1 for "no unit": one register
+    static_assert(HZ <= 16 && HY <= 32 && HX <= 64 && TILE_B / 16 < 65536, "staging unit packing");
+    int upk[ITERS];
+    constexpr bool TIGHT = NW == 8 && NT == 1;     // the 128-VGPR variants recompute uvox from upk (5 VALU) instead of holding it
+    unsigned uvox[TIGHT ? 1 : ITERS];
+    const int HW = g.H * g.W;
+    auto uvox_of = [&](int it) -> unsigned {
+        if constexpr (!TIGHT) return uvox[it];
+        else { const int uc = upk[it]; return (unsigned)(__umul24(uc & 15, HW) + __umul24((uc >> 4) & 31, g.W) + ((uc >> 9) & 63)); }
+    };
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int u = tid + it * NTHR;
         const int hv = u / G, hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
-        ucoord[it] = u < UNITS ? (hz | (hy << 10) | (hx << 20)) : -1;
-        ulds[it] = SWZ ? ((hz * HY + hy) * HXP + hx) * 64 + ((lg ^ (((hx >> 2) & 1) << 1)) << 4) : hv * VS + lg * 16;
-        uvox[it] = (unsigned)((hz * g.H + hy) * g.W + hx);
+        const int lds_off = SWZ ? ((hz * HY + hy) * HXP + hx) * 64 + ((lg ^ (((hx >> 2) & 1) << 1)) << 4) : hv * VS + lg * 16;
+        upk[it] = u < UNITS ? (hz | (hy << 4) | (hx << 9) | ((lds_off >> 4) << 15)) : -1;
+        if constexpr (!TIGHT) uvox[it] = (unsigned)((hz * g.H + hy) * g.W + hx);
     }
-    unsigned mvox[MTW];             // same for the outputs of this lane's m-tiles (non-scatter kinds)
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) mvox[i] = (unsigned)((mz[i] * a.oH + my[i]) * a.oW + mx[i]);
-    uint4 R[ITERS], RW[WITERS];
+    // RW is a native vector type: with the HIP uint4 struct the copies became llvm.memcpy global->private->LDS that SROA left in
+    // scratch memory (global_load, s_waitcnt, scratch_store per piece in every stage's prefetch)
+    uint4 R[ITERS];
+    bf16x8 RW[WITERS];
     // issue the global loads of stage st into R (no waiting)
     auto prefetch = [&](int st) {
         const int k = st / nchunk, q = st - k * nchunk;
-        if (WLDS && (nchunk > 1 || st == 0)) {
+        if (!ONE && WLDS && (nchunk > 1 || st == 0)) {
 #pragma unroll
             for (int it = 0; it < WITERS; ++it) {
                 const int pc = tid + it * NTHR;         // piece = (ks, n, lane)
                 if (pc < WPIECES) {
                     const int l = pc & 63, kn = pc >> 6, n = kn % NT, ks = kn / NT;
-                    RW[it] = *(const uint4*)(wp + (((size_t)q * KSTEPS + ks) * NTT + nt0 + n) * 64 + l);
+                    RW[it] = wp[(((size_t)q * KSTEPS + ks) * NTT + nt0 + n) * 64 + l];
                 }
             }
         }
@@ -226,39 +239,41 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
         const int iz0 = z0 * S - PAD, iy0 = y0 * S - PAD, ix0 = x0 * S - PAD;
         const int c = q * CK + lg * 8;
         const int s = (a.nsrc > 1 && c >= C0) ? 1 : 0;
-        const SrcDesc& sd = a.src[s];
+        // (selects, not a.src[s]: indexing a kernel argument dynamically makes the compiler copy it to scratch memory)
+        const char* sptr = (const char*)(s ? a.src[1].ptr : a.src[0].ptr);
+        const int sC = s ? a.src[1].C : C0;
         const long long org = ((long long)iz0 * g.H + iy0) * g.W + ix0;          // halo origin (may lie outside the volume)
-        const char* base = (const char*)sd.ptr + (org * sd.C + (c - (s ? C0 : 0))) * 2;
-        const unsigned vstride = (unsigned)sd.C * 2;
+        const char* base = sptr + (org * sC + (c - (s ? C0 : 0))) * 2;
+        const unsigned vstride = (unsigned)sC * 2;
         const bool interior = iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + HZ <= g.D && iy0 + HY <= g.H && ix0 + HX <= g.W;
         if (interior) {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
-                if (ucoord[it] >= 0) R[it] = *(const uint4*)(base + __umul24(uvox[it], vstride));
+                if ((it + 1) * NTHR <= UNITS || upk[it] >= 0) R[it] = *(const uint4*)(base + __umul24(uvox_of(it), vstride));
         } else {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int uc = ucoord[it];
-                const int gz = iz0 + (uc & 1023), gy = iy0 + ((uc >> 10) & 1023), gx = ix0 + (uc >> 20);
+                const int uc = upk[it];
+                const int gz = iz0 + (uc & 15), gy = iy0 + ((uc >> 4) & 31), gx = ix0 + ((uc >> 9) & 63);
                 R[it] = make_uint4(0u, 0u, 0u, 0u);
                 if (uc >= 0 && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
-                    R[it] = *(const uint4*)(base + __umul24(uvox[it], vstride));
+                    R[it] = *(const uint4*)(base + __umul24(uvox_of(it), vstride));
             }
         }
     };
     // write R to the LDS tile (sources are plain: a tensor with a pending norm/activation is read through its activated copy)
     auto commit = [&](int st) {
         const int k = st / nchunk, q = st - k * nchunk;
-        if (WLDS && (nchunk > 1 || st == 0)) {
+        if (!ONE && WLDS && (nchunk > 1 || st == 0)) {
 #pragma unroll
             for (int it = 0; it < WITERS; ++it) {
                 const int pc = tid + it * NTHR;
-                if (pc < WPIECES) *(uint4*)(smem + TILE_B + pc * 16) = RW[it];
+                if (pc < WPIECES) *(bf16x8*)(smem + TILE_B + pc * 16) = RW[it];
             }
         }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it)
-            if (ucoord[it] >= 0) *(uint4*)(smem + ulds[it]) = R[it];
+            if ((it + 1) * NTHR <= UNITS || upk[it] >= 0) *(uint4*)(smem + ((upk[it] >> 15) << 4)) = R[it];
     };
 
     float s1[NT][4], s2[NT][4];      // per-thread norm statistics of the stored outputs (channels nt0*16 + n*16 + gq*4 + r)
@@ -267,6 +282,16 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; }
 
+    if (ONE && WLDS) {   // the only chunk's filter fragments: global -> LDS once (visible after the first stage's barrier)
+#pragma unroll
+        for (int it = 0; it < WITERS; ++it) {
+            const int pc = tid + it * NTHR;
+            if (pc < WPIECES) {
+                const int l = pc & 63, kn = pc >> 6, n = kn % NT, ks = kn / NT;
+                *(bf16x8*)(smem + TILE_B + pc * 16) = wp[((size_t)ks * NTT + nt0 + n) * 64 + l];
+            }
+        }
+    }
     if (nst > 0) prefetch(0);
     for (int st = 0; st < nst; ++st) {
         const int k = st / nchunk, q = st - k * nchunk;
@@ -329,14 +354,15 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
             }
             int d = (a.nout > 1 && c >= a.outC[0]) ? 1 : 0;
             int cd = c - (d ? a.outC[0] : 0);
-            char* obase = (char*)a.out[d];
-            const int oC = a.outC[d], oacc = a.out_acc[d];
+            char* obase = (char*)(d ? a.out[1] : a.out[0]);
+            const int oC = d ? a.outC[1] : a.outC[0], oacc = d ? a.out_acc[1] : a.out_acc[0];
             // non-scatter kinds: address = tile origin (uniform) + this lane's precomputed voxel offset
             const bool edge = z0 + BZ > a.oD || y0 + BY > a.oH || x0 + BX > a.oW;
             char* tbase = obase + ((((long long)z0 * a.oH + y0) * a.oW + x0) * oC + cd) * 2;
 #pragma unroll
             for (int i = 0; i < MTW; ++i) {
-                int gz = z0 + mz[i], gy = y0 + my[i], gx = x0 + mx[i];
+                const int mt = wave * MTW + i;    // recomputed (cheap, constant divisors) rather than held in registers
+                int gz = z0 + mt / (BY / TYM), gy = y0 + (mt % (BY / TYM)) * TYM + (j / TXM), gx = x0 + j % TXM;
                 if (SC) { gz = 2 * gz + tz; gy = 2 * gy + ty; gx = 2 * gx + tx; }
                 if (((!SC && !edge) || (gz < a.oD && gy < a.oH && gx < a.oW)) && obase) {
                     uint2* p;
@@ -467,9 +493,10 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
                 if (qb + qq < nq) {
                     const int c = (q0 + qb + qq) * 32 + lg * 8;
                     const int sidx = (a.nsrc > 1 && c >= C0) ? 1 : 0;
-                    const SrcDesc& sd = a.src[sidx];
-                    const char* base = (const char*)sd.ptr + (org * sd.C + (c - (sidx ? C0 : 0))) * 2;
-                    const unsigned vstride = (unsigned)sd.C * 2;
+                    const char* sptr = (const char*)(sidx ? a.src[1].ptr : a.src[0].ptr);
+                    const int sC = sidx ? a.src[1].C : C0;
+                    const char* base = sptr + (org * sC + (c - (sidx ? C0 : 0))) * 2;
+                    const unsigned vstride = (unsigned)sC * 2;
 #pragma unroll
                     for (int it = 0; it < ITERS; ++it) {
                         R[qq][it] = make_uint4(0u, 0u, 0u, 0u);
@@ -533,8 +560,8 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
         }
         const int d = (a.nout > 1 && c >= a.outC[0]) ? 1 : 0;
         const int cd = c - (d ? a.outC[0] : 0);
-        char* obase = (char*)a.out[d];
-        const int oC = a.outC[d], oacc = a.out_acc[d];
+        char* obase = (char*)(d ? a.out[1] : a.out[0]);
+        const int oC = d ? a.outC[1] : a.outC[0], oacc = d ? a.out_acc[1] : a.out_acc[0];
         const int mz = wave / RG, my = (wave % RG) * TYM + j / TXM, mx = j % TXM;
         const int gz = z0 + mz, gy = y0 + my, gx = x0 + mx;
         if (gz < a.oD && gy < a.oH && gx < a.oW && obase) {
@@ -589,7 +616,7 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     // persistent grid: at most ~2 blocks per CU in total (256 CUs), tiles strided over them
@@ -601,7 +628,18 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW><<<grid, NW * 64, lds, s>>>(a);
+    if constexpr (NW == 8 && NT == 1 && !SC) {
+        if (a.g.Cin == CK) {
+            static bool attr1_done = false;
+            if (!attr1_done) {
+                (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr1_done = true;
+            }
+            k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW, true><<<grid, NW * 64, lds, s>>>(a);
+            return gx;
+        }
+    }
+    k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW, false><<<grid, NW * 64, lds, s>>>(a);
     return gx;
 }
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> static int launch_nt(const MfmaConvArgs& a, hipStream_t s) {
