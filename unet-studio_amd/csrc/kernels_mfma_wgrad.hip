@@ -11,8 +11,8 @@
 //     the step, identically for A and B.
 //   * a block = PI x PJ (ca-tile, cb-tile) pairs, one pair per wave (4/(PI*PJ) waves per pair split the K-steps);
 //     every wave keeps all T tap accumulators in registers (27 taps: 108 VGPRs) across the block's tiles.
-//   * no float atomics: each block writes its partial to a slab [split][T][Ca][Cb]; a second kernel sums the slabs
-//     in a fixed order and adds into the fp32 gradient in torch layout (+=, as .grad accumulates).
+//   * no float atomics: each block writes its partial to a slab [split][Cb][Ca][T] (the gradient's layout); a second kernel
+//     sums the slabs in a fixed order and adds into the fp32 gradient (+=, as .grad accumulates).
 //   * conv: dL/dbias = sum_v dy[v][co] is accumulated by the threads that stage dy (blocks of ca-tile 0 only).
 #include "mfma_util.h"
 
@@ -26,7 +26,7 @@ struct MfmaWgradArgs {
     SrcDesc asrc[2];   // halo side (may be a channel concat)
     int nasrc;
     SrcDesc bsrc;      // tile side
-    float* slab;       // [nsplit][T][Ca][Cb]
+    float* slab;       // [nsplit][Cb][Ca][T]
     float* bias_slab;  // [nsplit][Cb] or nullptr: per-channel sums of the RAW tile-side tensor
     int tiles_x, tiles_y, tiles_z;
 };
@@ -194,13 +194,19 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
         }
         __syncthreads();
     }
+    // The slab has the gradient's own layout [cb][ca][t] (torch: [Cout][Cin][k^3], conv_trans [Cin][Cout][8]), so the reduce
+    // kernel is a linear, coalesced sum (the [t][ca][cb] slab of the first version made it a 4-byte read-modify-write
+    // scatter).  A lane owns cb = il and ca = gq*4 .. +3: its 4*T values are one contiguous, 16-B aligned run.
     if (kw == 0) {
-        const int ci = (ciB + it_) * 16 + gq * 4, co = (coB + jt) * 16 + il;
-        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout;
+        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout +
+                    (((size_t)(coB + jt) * 16 + il) * g.Cin + (size_t)(ciB + it_) * 16 + gq * 4) * T;
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int e = 0; e < T; ++e) {   // elements 4e .. 4e+3 of the run [r][t]
+            f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sl[((size_t)t * g.Cin + ci + r) * g.Cout + co] = acc[t][r];
+            for (int k = 0; k < 4; ++k) v[k] = acc[(4 * e + k) % T][(4 * e + k) / T];
+            *(f32x4*)(sl + 4 * e) = v;
+        }
     }
     if (do_bias) {
         // threads with equal ub hold partial sums of the same 8 channels: reduce over the 256/GB of them
@@ -219,34 +225,40 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
     }
 }
 
-// dw[(cb*Ca + ca)*T + t] += sum_split slab[split][t][ca][cb];  db[cb] += sum_split bias_slab[split][cb].
-// 32 consecutive outputs x 8 split lanes per block: coalesced slab reads, fixed summation order.
+// dw[i] += sum_split slab[split][i]  (slab and dw share the layout);  db[cb] += sum_split bias_slab[split][cb].
+// LX consecutive outputs x 256/LX split lanes per block: coalesced slab reads, fixed summation order.
+template <int LX>
 __global__ void __launch_bounds__(256) k_mfma_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ bias_slab, int nsplit,
-                                                           int T, int Ca, int Cb, float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ double red[8][32];
-    const int64_t n = (int64_t)T * Ca * Cb, ntot = n + (db && bias_slab ? Cb : 0);
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + lx;
+                                                           int64_t n, int Cb, float* __restrict__ dw, float* __restrict__ db) {
+    constexpr int LY = 256 / LX;
+    __shared__ double red[LY][LX];
+    const int64_t ntot = n + (db && bias_slab ? Cb : 0);
+    const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+    const int64_t i = (int64_t)blockIdx.x * LX + lx;
     double s = 0.0;
     if (i < n) {
-        for (int k = ly; k < nsplit; k += 8) s += slab[(int64_t)k * n + i];
+        for (int k = ly; k < nsplit; k += LY) s += slab[(int64_t)k * n + i];
     } else if (i < ntot) {
-        for (int k = ly; k < nsplit; k += 8) s += bias_slab[(int64_t)k * Cb + (i - n)];
+        for (int k = ly; k < nsplit; k += LY) s += bias_slab[(int64_t)k * Cb + (i - n)];
     }
-    red[ly][lx] = s;
-    __syncthreads();
-    if (ly == 0 && i < ntot) {
-        double tot = 0.0;
+    if (LY > 1) {
+        red[ly][lx] = s;
+        __syncthreads();
+        if (ly == 0) {
+            s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tot += red[k][lx];
-        if (i < n) {
-            int cb = (int)(i % Cb); int64_t r = i / Cb;
-            int ca = (int)(r % Ca); int t = (int)(r / Ca);
-            dw[((int64_t)cb * Ca + ca) * T + t] += (float)tot;
-        } else {
-            db[i - n] += (float)tot;
+            for (int k = 0; k < LY; ++k) s += red[k][lx];
         }
     }
+    if (ly == 0 && i < ntot) {
+        if (i < n) dw[i] += (float)s;
+        else db[i - n] += (float)s;
+    }
+}
+static void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, int64_t n, int Cb, float* dw, float* db, hipStream_t s) {
+    const int64_t ntot = n + (db && bias_slab ? Cb : 0);
+    if (nsplit <= 16) k_mfma_wgrad_reduce<256><<<cdiv64(ntot, 256), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
+    else k_mfma_wgrad_reduce<32><<<cdiv64(ntot, 32), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
 }
 
 static bool chan16(const ConvGeom& g, const SrcDesc* src, int nsrc) {
@@ -343,8 +355,7 @@ void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, con
         else if (g.Wo > 4) launch_wgrad_p<2, 3, 1, 2, 8, 8>(a, c, s);
         else launch_wgrad_p<2, 3, 1, 4, 8, 4>(a, c, s);
     }
-    int64_t n = (int64_t)27 * g.Cin * g.Cout + (db ? g.Cout : 0);
-    k_mfma_wgrad_reduce<<<cdiv64(n, 32), 256, 0, s>>>(a.slab, a.bias_slab, c.nsplit, 27, g.Cin, g.Cout, dw, db);
+    wgrad_reduce(a.slab, a.bias_slab, c.nsplit, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
 }
 
 // conv_trans wgrad (g = forward geometry of the conv_trans: D,H,W coarse input, Do,Ho,Wo fine output).
@@ -361,9 +372,8 @@ void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* 
     if (g.W >= 12) launch_wgrad_p<2, 2, 0, 2, 4, 16>(a, c, s);
     else if (g.W > 4) launch_wgrad_p<2, 2, 0, 2, 8, 8>(a, c, s);
     else launch_wgrad_p<2, 2, 0, 4, 8, 4>(a, c, s);
-    // slab[t][ca = co][cb = ci] -> dw[(ci*Cout + co)*8 + t]
-    int64_t n = (int64_t)8 * g.Cin * g.Cout;
-    k_mfma_wgrad_reduce<<<cdiv64(n, 32), 256, 0, s>>>(a.slab, nullptr, c.nsplit, 8, g.Cout, g.Cin, dw, nullptr);
+    // slab[cb = ci][ca = co][t] = the layout of dw ([Cin][Cout][2][2][2])
+    wgrad_reduce(a.slab, nullptr, c.nsplit, (int64_t)8 * g.Cin * g.Cout, g.Cin, dw, nullptr, s);
 }
 
 }  // namespace unet
