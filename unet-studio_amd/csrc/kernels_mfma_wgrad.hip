@@ -14,6 +14,7 @@
 //   * no float atomics: each block writes its partial to a slab [split][Cb][Ca][T] (the gradient's layout); a second kernel
 //     sums the slabs in a fixed order and adds into the fp32 gradient (+=, as .grad accumulates).
 //   * conv: dL/dbias = sum_v dy[v][co] is accumulated by the threads that stage dy (blocks of ca-tile 0 only).
+#include <type_traits>
 #include "mfma_util.h"
 
 namespace unet {
@@ -66,94 +67,118 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
-    // staging roles (fixed per thread): A units (plane, half) and B units (plane, half)
+    // staging roles (fixed per thread): A units (plane, half) and B units (plane, half).  Sources are plain (a tensor with a
+    // pending norm/activation is read through its activated copy).
     constexpr int GA = PI * 2, GB = PJ * 2;
     const int ua = tid % GA, ub = tid % GB;
     const int ca = (ciB + (ua >> 1)) * 16 + (ua & 1) * 8;
     const int sa = (a.nasrc > 1 && ca >= C0) ? 1 : 0;
-    const SrcDesc& sd = a.asrc[sa];
     const int cla = ca - (sa ? C0 : 0);
-    float sc[8], sh[8];
-    const bool xf = sd.scale != nullptr;
-    if (xf) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = sd.scale[cla + e]; sh[e] = sd.shift[cla + e]; }
-    }
-    const int act = sd.act;
-    const char* abase = (const char*)sd.ptr + (size_t)cla * 2;
+    const int aC = sa ? a.asrc[1].C : C0;
+    const char* abase = (const char*)(sa ? a.asrc[1].ptr : a.asrc[0].ptr) + (size_t)cla * 2;
     const int cb = (coB + (ub >> 1)) * 16 + (ub & 1) * 8;
     const char* bbase = (const char*)a.bsrc.ptr + (size_t)cb * 2;
-    float scb[8], shb[8];
-    const bool xfb = a.bsrc.scale != nullptr;
-    if (xfb) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { scb[e] = a.bsrc.scale[cb + e]; shb[e] = a.bsrc.shift[cb + e]; }
-    }
-    const int actb = a.bsrc.act;
     const bool do_bias = a.bias_slab != nullptr && ciB == 0;
 
-    // staging units of this thread, decoded once (coordinates packed 10 bits each, -1 = none; LDS byte offsets)
+    // staging units of this thread, decoded once: coordinates (z 4 bits | y 5 << 4 | x 6 << 9) | LDS offset / 16 << 15 (or -1),
+    // and the voxel offset from the tile's origin in the source volume (address = tile base + offset * voxel stride)
     constexpr int UNITS_A = NVA * GA, ITERS_A = (UNITS_A + 255) / 256;
     constexpr int UNITS_B = NVB * GB, ITERS_B = (UNITS_B + 255) / 256;
-    int ua_coord[ITERS_A], ua_lds[ITERS_A], ub_coord[ITERS_B], ub_lds[ITERS_B];
+    static_assert(HZ <= 16 && HY <= 32 && HX <= 64, "staging unit packing");
+    int ua_pk[ITERS_A], ub_pk[ITERS_B];
+    unsigned ua_vox[ITERS_A], ub_vox[ITERS_B];
 #pragma unroll
     for (int itr = 0; itr < ITERS_A; ++itr) {
         const int u = tid + itr * 256, hv = u / GA;
         const int hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
-        ua_coord[itr] = u < UNITS_A ? (hz | (hy << 10) | (hx << 20)) : -1;
-        ua_lds[itr] = (ua >> 1) * PLANE_A + hv * 32 + (ua & 1) * 16;
+        const int lds_off = (ua >> 1) * PLANE_A + hv * 32 + (ua & 1) * 16;
+        ua_pk[itr] = u < UNITS_A ? (hz | (hy << 4) | (hx << 9) | ((lds_off >> 4) << 15)) : -1;
+        ua_vox[itr] = (unsigned)((hz * g.H + hy) * g.W + hx);
     }
 #pragma unroll
     for (int itr = 0; itr < ITERS_B; ++itr) {
         const int u = tid + itr * 256, tv = u / GB;
         const int tz = tv / (BY * BX), tr = tv % (BY * BX), ty = tr / BX, tx = tr % BX;
-        ub_coord[itr] = u < UNITS_B ? (tz | (ty << 10) | (tx << 20)) : -1;
-        ub_lds[itr] = B_OFF + (ub >> 1) * PLANE_B + tv * 32 + (ub & 1) * 16;
+        const int lds_off = B_OFF + (ub >> 1) * PLANE_B + tv * 32 + (ub & 1) * 16;
+        ub_pk[itr] = u < UNITS_B ? (tz | (ty << 4) | (tx << 9) | ((lds_off >> 4) << 15)) : -1;
+        ub_vox[itr] = (unsigned)((tz * g.Ho + ty) * g.Wo + tx);
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Prefetch registers are native vectors (HIP's uint4 struct copies become memcpy's that stay in scratch memory).
+    bf16x8 RA[ITERS_A], RB[ITERS_B];
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+    auto prefetch = [&](int tile, auto direct) {   // direct: store every unit to LDS as it arrives (no prefetch registers)
+        constexpr bool DIRECT = decltype(direct)::value;
         const int ox0 = (tile % a.tiles_x) * BX, oy0 = ((tile / a.tiles_x) % a.tiles_y) * BY, oz0 = (tile / (a.tiles_x * a.tiles_y)) * BZ;
         const int ix0 = ox0 * S - PAD, iy0 = oy0 * S - PAD, iz0 = oz0 * S - PAD;
-        __syncthreads();
-        // ---- stage A: halo tile (units decoded once per thread: ua_coord / ua_lds) ----
-        {
-            const size_t vstride = (size_t)sd.C * 2;
+        const char* at = abase + ((((long long)iz0 * g.H + iy0) * g.W + ix0) * aC) * 2;
+        const char* bt = bbase + ((((long long)oz0 * g.Ho + oy0) * g.Wo + ox0) * g.Cout) * 2;
+        const unsigned avs = (unsigned)aC * 2, bvs = (unsigned)g.Cout * 2;
+        const bool ain = iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + HZ <= g.D && iy0 + HY <= g.H && ix0 + HX <= g.W;
+        const bool bin = oz0 + BZ <= g.Do && oy0 + BY <= g.Ho && ox0 + BX <= g.Wo;
 #pragma unroll
-            for (int itr = 0; itr < ITERS_A; ++itr) {
-                const int uc = ua_coord[itr];
-                if (uc >= 0) {
-                    const int gz = iz0 + (uc & 1023), gy = iy0 + ((uc >> 10) & 1023), gx = ix0 + (uc >> 20);
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if ((unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
-                        v = transform8(*(const uint4*)(abase + (((size_t)gz * g.H + gy) * g.W + gx) * vstride), xf, sc, sh, act);
-                    *(uint4*)(smem + ua_lds[itr]) = v;
-                }
+        for (int itr = 0; itr < ITERS_A; ++itr) {
+            const int uc = ua_pk[itr];
+            bool ok = (itr + 1) * 256 <= UNITS_A || uc >= 0;
+            if (!ain) {
+                const int gz = iz0 + (uc & 15), gy = iy0 + ((uc >> 4) & 31), gx = ix0 + ((uc >> 9) & 63);
+                ok = ok && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             }
+            bf16x8 v = zero8;
+            if (ok) v = *(const bf16x8*)(at + __umul24(ua_vox[itr], avs));
+            if constexpr (DIRECT) { if ((itr + 1) * 256 <= UNITS_A || uc >= 0) *(bf16x8*)(smem + ((uc >> 15) << 4)) = v; }
+            else RA[itr] = v;
         }
-        // ---- stage B: tile (+ bias partial sums of the raw values) ----
-        {
-            const size_t vstride = (size_t)g.Cout * 2;
 #pragma unroll
-            for (int itr = 0; itr < ITERS_B; ++itr) {
-                const int uc = ub_coord[itr];
-                if (uc >= 0) {
-                    const int gz = oz0 + (uc & 1023), gy = oy0 + ((uc >> 10) & 1023), gx = ox0 + (uc >> 20);
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (gz < g.Do && gy < g.Ho && gx < g.Wo) {
-                        v = *(const uint4*)(bbase + (((size_t)gz * g.Ho + gy) * g.Wo + gx) * vstride);
-                        if (do_bias) {
-                            bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
-                            bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
-                        }
-                        v = transform8(v, xfb, scb, shb, actb);
+        for (int itr = 0; itr < ITERS_B; ++itr) {
+            const int uc = ub_pk[itr];
+            bool ok = (itr + 1) * 256 <= UNITS_B || uc >= 0;
+            if (!bin) {
+                const int gz = oz0 + (uc & 15), gy = oy0 + ((uc >> 4) & 31), gx = ox0 + ((uc >> 9) & 63);
+                ok = ok && gz < g.Do && gy < g.Ho && gx < g.Wo;
+            }
+            bf16x8 v = zero8;
+            if (ok) v = *(const bf16x8*)(bt + __umul24(ub_vox[itr], bvs));
+            if constexpr (DIRECT) {
+                if ((itr + 1) * 256 <= UNITS_B || uc >= 0) {
+                    *(bf16x8*)(smem + ((uc >> 15) << 4)) = v;
+                    if (do_bias) {
+                        const uint4 w = __builtin_bit_cast(uint4, v);
+                        bsum[0] += bf_lo(w.x); bsum[1] += bf_hi(w.x); bsum[2] += bf_lo(w.y); bsum[3] += bf_hi(w.y);
+                        bsum[4] += bf_lo(w.z); bsum[5] += bf_hi(w.z); bsum[6] += bf_lo(w.w); bsum[7] += bf_hi(w.w);
                     }
-                    *(uint4*)(smem + ub_lds[itr]) = v;
+                }
+            } else RB[itr] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int itr = 0; itr < ITERS_A; ++itr)
+            if ((itr + 1) * 256 <= UNITS_A || ua_pk[itr] >= 0) *(bf16x8*)(smem + ((ua_pk[itr] >> 15) << 4)) = RA[itr];
+#pragma unroll
+        for (int itr = 0; itr < ITERS_B; ++itr) {
+            if ((itr + 1) * 256 <= UNITS_B || ub_pk[itr] >= 0) {
+                *(bf16x8*)(smem + ((ub_pk[itr] >> 15) << 4)) = RB[itr];
+                if (do_bias) {
+                    const uint4 v = __builtin_bit_cast(uint4, RB[itr]);
+                    bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+                    bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
                 }
             }
         }
+    };
+
+    const char* pa = smem + it_ * PLANE_A + p4 * 8;
+    const char* pb = smem + B_OFF + jt * PLANE_B + p4 * 8;
+    // PREF: the next tile's global loads ride in registers through the MFMA phase (27 tap accumulators = 108 VGPRs leave room
+    // for ~10 staging units per thread); the wider configurations load and store back to back as before.
+    constexpr bool PREF = KD == 2 || (S == 1 && PI == 1 && ITERS_A + ITERS_B <= 8);
+    if (PREF && (int)blockIdx.x < ntiles) prefetch(blockIdx.x, std::false_type{});
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                 // every wave is done reading the previous tile
+        if constexpr (PREF) commit(); else prefetch(tile, std::true_type{});
         __syncthreads();
-        // ---- MFMA: this wave's K-steps ----
-        const char* pa = smem + it_ * PLANE_A + p4 * 8;
-        const char* pb = smem + B_OFF + jt * PLANE_B + p4 * 8;
+        if (PREF && tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x, std::false_type{});   // in flight during the MFMAs below
+        // ---- MFMA: this wave's K-steps; the tr-reads of tap t+1 are issued before the MFMA of tap t ----
 #pragma unroll 1
         for (int s = kw; s < KSTEPS; s += WPP) {
             int ao[2], bo[2];
@@ -165,12 +190,18 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
                 ao[r] = ((z * S * HY + y * S) * HX + x * S) * 32;
                 bo[r] = ((z * BY + y) * BX + x) * 32;
             }
-            bf16x8 bfrag = tr_read2(pb + bo[0], pb + bo[1]);
+            const bf16x8 bfrag = tr_read2(pb + bo[0], pb + bo[1]);
+            bf16x8 abuf[2];
+            abuf[0] = tr_read2(pa + ao[0], pa + ao[1]);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const int toff = (((t / (KD * KD)) * HY + (t / KD) % KD) * HX + t % KD) * 32;
-                bf16x8 afrag = tr_read2(pa + ao[0] + toff, pa + ao[1] + toff);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+                if (t + 1 < T) {
+                    const int t1 = t + 1, toff = (((t1 / (KD * KD)) * HY + (t1 / KD) % KD) * HX + t1 % KD) * 32;
+                    abuf[t1 & 1] = tr_read2(pa + ao[0] + toff, pa + ao[1] + toff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(abuf[t & 1], bfrag, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -264,7 +295,7 @@ static void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, 
 static bool chan16(const ConvGeom& g, const SrcDesc* src, int nsrc) {
     if (g.Cin % 16 || g.Cout % 16) return false;
     for (int s = 0; s < nsrc; ++s)
-        if (src[s].C % 16) return false;
+        if (src[s].C % 16 || src[s].scale || src[s].act) return false;   // plain sources only (engine: activated copies)
     return true;
 }
 bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
@@ -281,6 +312,10 @@ static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
     int cat = Ca / 16, cbt = Cb / 16;
     if (kind == 0) {
         c.pi = cat % 2 == 0 ? 2 : 1; c.pj = cbt % 2 == 0 ? 2 : 1;
+        // One (ca, cb) pair per block with the 4 waves splitting K is what lets the next tile's loads ride in registers
+        // (PREF); measured on the whole step: 5.15 ms with 2x2 pairs, 4.95 ms with single pairs at W >= 12.
+        static const int p11 = getenv("UNET_WGRAD_P11") ? atoi(getenv("UNET_WGRAD_P11")) : 1;   // experiment knob
+        if ((p11 == 1 && bW >= 12) || p11 == 3) { c.pi = 1; c.pj = 1; }
         if (bW >= 12) { c.bz = 2; c.by = 8; c.bx = 16; }
         else if (bW > 4) { c.bz = 4; c.by = 8; c.bx = 8; }
         else { c.bz = 4; c.by = 8; c.bx = 4; }
