@@ -171,6 +171,10 @@ struct unet_plan {
                 b = wgrad_small_scratch_bytes(cg);
                 if (b > wmax) wmax = b;
             }
+            if (op.kind == OP_CONV && head_supported(cg, op.nsrc)) {
+                b = head_bwd_scratch_bytes(cg);
+                if (b > wmax) wmax = b;
+            }
             if (op.kind == OP_CONVT && impl == UNET_IMPL_AUTO) {
                 SrcDesc sd[2];
                 for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
@@ -289,6 +293,10 @@ struct Exec {
                         int rows = launch_mfma_conv_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst),
                                                         want_stats ? partial() : nullptr, s);
                         if (want_stats) fused_blocks[T.norm] = rows;
+                    } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level >= 0 && head_supported(cg, op.nsrc)) {
+                        // a head: results[level] straight from the source tensor (the channels-last copy only if nobody asked for the level)
+                        float* o = outs[op.out_level];
+                        launch_head_fwd(p.dtype, cg, sd[0], params[op.weight], params[op.bias], o ? nullptr : tptr(op.dst), o, s);
                     } else if (op.kind == OP_CONV) {
                         launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
@@ -390,6 +398,14 @@ struct Exec {
             int t = op.dst;
             if ((op.kind == OP_CONV) && op.out_level >= 0) {
                 if (!(grad_outs && grad_outs[op.out_level])) continue;
+                if (p.impl == UNET_IMPL_AUTO && head_supported(geom(op), op.nsrc)) {
+                    // fused head backward: dL/dW, dL/db and dL/d(source view) in one pass over (source, dL/dresults[level])
+                    DstGrad dgh = dst_of(op.src[0]);
+                    launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
+                                    gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                    if (dgh.ptr) mark(op);
+                    continue;
+                }
                 launch_import_grad(p.dtype, grad_outs[op.out_level], gptr(t), g.tensors[t].C, g.tensors[t].voxels(), 0, s);
                 init[t] = 1;
             }

@@ -140,6 +140,14 @@ size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s);
 // wgrad of layers with <= 1024 weights (Cin = 1 first conv, 6-channel heads): row-staged, HBM-bound
+// 1x1x1 heads (Cout <= 8, Cin = 16 * 2^k <= 256, one plain or viewed source): forward writes results[level] (fp32 NCDHW) and/or
+// the channels-last tensor; backward = dL/dW (+=), dL/db (+=) and dL/d(source view) in one pass, dy as fp32 NCDHW or channels-last
+bool head_supported(const ConvGeom& g, int nsrc);
+size_t head_bwd_scratch_bytes(const ConvGeom& g);
+void launch_head_fwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* w, const float* bias, void* y, float* out_ncdhw,
+                     hipStream_t s);
+void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* dy_ncdhw, const void* dy_cl, const float* w,
+                     DstGrad dst, float* dw, float* db, void* scratch, hipStream_t s);
 bool wgrad_small_supported(const ConvGeom& g, int nsrc);
 size_t wgrad_small_scratch_bytes(const ConvGeom& g);
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,

@@ -756,6 +756,156 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_first(Wgrad
     });
 }
 
+// ---- the 1x1x1 heads (Conv3d(C, out_count, 1), unet.cpp:157-160), forward and fused backward ----------------------------------
+// Lanes = (voxel, 16-channel chunk) as in k_wgrad_head; the filter ([Cout][Cin] fp32, torch layout, no pack) sits in LDS.
+template <typename T> __device__ __forceinline__ void load_chunk16(const SrcDesc& src, bool plain, int64_t v, int c0, bool ok, float (&x)[16]) {
+    if constexpr (sizeof(T) == 2) {
+        if (plain) {
+            uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+            if (ok) {
+                const uint4* q = (const uint4*)((const bf16*)src.ptr + v * src.C + c0);
+                r0 = q[0]; r1 = q[1];
+            }
+            const unsigned w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { x[2 * k] = __uint_as_float(w[k] << 16); x[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+            return;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ok ? view_ld<T>(src, v, c0 + k) : 0.f;
+}
+
+struct HeadArgs {
+    SrcDesc src;
+    const float* w;        // [Cout][Cin]
+    const float* bias;     // [Cout] or nullptr
+    int Cin, Cout, lc;     // lc = log2(Cin / 16)
+    int64_t S;
+    // forward
+    void* y;               // channels-last [S][Cout] in T, or nullptr
+    float* out;            // fp32 NCDHW [Cout][S] (results[level]), or nullptr
+    // backward
+    const float* dy_planes;  // fp32 NCDHW gradient of results[level] ...
+    const void* dy_cl;       // ... or channels-last [S][Cout] in T
+    DstGrad dst;             // dL/d(source view): written or accumulated; ptr may be null
+    float* slab;             // [gridDim.x][Cout*Cin + Cout] wgrad + bias partials (nullptr: no parameter gradients)
+};
+
+template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_fwd(HeadArgs a) {
+    extern __shared__ float sm[];      // [CO][Cin] (rows >= Cout zero)
+    for (int i = threadIdx.x; i < CO * a.Cin; i += 256) sm[i] = i < a.Cout * a.Cin ? a.w[i] : 0.f;
+    __syncthreads();
+    const int nchunk = 1 << a.lc, chunk = threadIdx.x & (nchunk - 1), c0 = chunk * 16;
+    const int64_t vstride = ((int64_t)gridDim.x * 256) >> a.lc;
+    const bool plain = !a.src.scale && a.src.act == 0;
+    float b[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) b[c] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+    // the grid covers whole waves of (voxel, chunk) items: every lane takes part in the shuffles
+    for (int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc; v0 < ((a.S + 63) & ~(int64_t)63); v0 += vstride) {
+        const bool ok = v0 < a.S;
+        float x[16], o[CO];
+        load_chunk16<T>(a.src, plain, v0, c0, ok, x);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float4* wr = (const float4*)(sm + c * a.Cin + c0);
+            float r = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const float4 w4 = wr[k4];
+                r = fmaf(x[4 * k4], w4.x, r); r = fmaf(x[4 * k4 + 1], w4.y, r); r = fmaf(x[4 * k4 + 2], w4.z, r); r = fmaf(x[4 * k4 + 3], w4.w, r);
+            }
+            for (int m = 1; m < nchunk; m <<= 1) r += __shfl_xor(r, m);
+            o[c] = r + b[c];
+        }
+        if (ok && chunk == 0) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                if (c < a.Cout) {
+                    if (a.out) a.out[(int64_t)c * a.S + v0] = o[c];
+                    if (a.y) st<T>((T*)a.y, v0 * a.Cout + c, o[c]);
+                }
+            }
+        }
+    }
+}
+
+// dL/dW, dL/db and dL/d(source) of a head in one pass over (source, dy): replaces gradient import + wgrad + dgrad
+template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_bwd(HeadArgs a) {
+    extern __shared__ float sm[];      // [CO][Cin] filter, later the wgrad reduction scratch
+    constexpr int NACC = CO * 16 + CO;
+    for (int i = threadIdx.x; i < CO * a.Cin; i += 256) sm[i] = i < a.Cout * a.Cin ? a.w[i] : 0.f;
+    __syncthreads();
+    const int nchunk = 1 << a.lc, chunk = threadIdx.x & (nchunk - 1), c0 = chunk * 16;
+    const int64_t vstride = ((int64_t)gridDim.x * 256) >> a.lc;
+    const bool plain = !a.src.scale && a.src.act == 0;
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+    for (int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc; v0 < a.S; v0 += vstride) {
+        float x[16], d[CO];
+        load_chunk16<T>(a.src, plain, v0, c0, true, x);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            d[c] = 0.f;
+            if (c < a.Cout) d[c] = a.dy_planes ? a.dy_planes[(int64_t)c * a.S + v0] : ld<T>((const T*)a.dy_cl, v0 * a.Cout + c);
+        }
+        if (a.slab) {
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[c * 16 + k] = fmaf(d[c], x[k], acc[c * 16 + k]);
+                acc[CO * 16 + c] += d[c];
+            }
+        }
+        if (a.dst.ptr) {
+            float g[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) g[k] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const float4* wr = (const float4*)(sm + c * a.Cin + c0);
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 w4 = wr[k4];
+                    g[4 * k4] = fmaf(d[c], w4.x, g[4 * k4]); g[4 * k4 + 1] = fmaf(d[c], w4.y, g[4 * k4 + 1]);
+                    g[4 * k4 + 2] = fmaf(d[c], w4.z, g[4 * k4 + 2]); g[4 * k4 + 3] = fmaf(d[c], w4.w, g[4 * k4 + 3]);
+                }
+            }
+            if constexpr (sizeof(T) == 2) {
+                uint4* q = (uint4*)((bf16*)a.dst.ptr + v0 * a.dst.C + c0);
+                if (a.dst.accumulate) {
+                    const uint4 r0 = q[0], r1 = q[1];
+                    const unsigned w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { g[2 * k] += __uint_as_float(w[k] << 16); g[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+                }
+                unsigned pk[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bf16 lo = __float2bfloat16(g[2 * k]), hi = __float2bfloat16(g[2 * k + 1]);
+                    pk[k] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                }
+                q[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]); q[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            } else {
+                float* q = (float*)a.dst.ptr + v0 * a.dst.C + c0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) q[k] = a.dst.accumulate ? q[k] + g[k] : g[k];
+            }
+        }
+    }
+    if (a.slab) {
+        __syncthreads();               // the filter in LDS is no longer needed
+        const int Cin = a.Cin, Cout = a.Cout, O = Cin * Cout;
+        small_wgrad_epilogue<NACC>(acc, nchunk, sm, a.slab + (int64_t)blockIdx.x * (O + Cout), [=](int ch, int i) {
+            if (i < CO * 16) { int c = i / 16, k = i % 16; return c < Cout ? c * Cin + ch * 16 + k : -1; }
+            int c = i - CO * 16;
+            return (ch == 0 && c < Cout) ? O + c : -1;
+        });
+    }
+}
+
 static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 static bool wgrad_head_ok(const ConvGeom& g, int nsrc) {
     return nsrc == 1 && g.ks == 1 && g.stride == 1 && g.Cout <= 8 && g.Cin % 16 == 0 && ilog2_exact(g.Cin / 16) >= 0 && g.Cin <= 256;
@@ -764,7 +914,7 @@ static bool wgrad_first_ok(const ConvGeom& g, int nsrc) {
     return nsrc == 1 && g.ks == 3 && g.stride == 1 && g.Cin == 1 && g.Cout % 4 == 0 && ilog2_exact(g.Cout / 4) >= 0 && g.Cout <= 64 &&
            g.W % 4 == 0 && g.W <= 256;
 }
-static int wgrad_reg_blocks(int64_t items) { int64_t nb = (items + 1023) / 1024; return nb < 1 ? 1 : (nb > 512 ? 512 : (int)nb); }
+static int wgrad_reg_blocks(int64_t items4) { int64_t nb = (items4 + 1023) / 1024; return nb < 1 ? 1 : (nb > 512 ? 512 : (int)nb); }
 static bool wgrad_rows_ok(const ConvGeom& g) {
     int k3 = g.ks * g.ks * g.ks;
     int WI = (g.Wo - 1) * g.stride + g.ks;
@@ -794,7 +944,7 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
         int nb;
         if (head) {
             a.lc = ilog2_exact(g.Cin / 16);
-            nb = wgrad_reg_blocks((S << a.lc) / 4);
+            nb = wgrad_reg_blocks((S << a.lc) * 4);
             const int CO = g.Cout <= 2 ? 2 : g.Cout <= 4 ? 4 : g.Cout <= 6 ? 6 : 8;
             const size_t lds = (size_t)4 * (1 << a.lc) * (CO * 17) * 4;
             switch (CO) {
@@ -823,6 +973,42 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
     UNET_DISPATCH(dtype, (k_wgrad_small<T><<<nb, 256, lds, s>>>(a)));
     slab_reduce(a.slab, nb, O, dw, s);
     if (db) launch_bias_grad(dtype, dy, g.Cout, (int64_t)g.Do * g.Ho * g.Wo, db, (float*)scratch + (size_t)nb * O, s);
+}
+
+// ---- heads: public launchers ----
+bool head_supported(const ConvGeom& g, int nsrc) { return wgrad_head_ok(g, nsrc); }
+size_t head_bwd_scratch_bytes(const ConvGeom& g) { return (size_t)512 * ((size_t)g.Cin * g.Cout + g.Cout) * 4 + 256; }
+template <typename T> static void head_launch(bool bwd, int CO, int nb, size_t lds, const HeadArgs& a, hipStream_t s) {
+    switch (CO) {
+        case 2: if (bwd) k_head_bwd<T, 2><<<nb, 256, lds, s>>>(a); else k_head_fwd<T, 2><<<nb, 256, lds, s>>>(a); break;
+        case 4: if (bwd) k_head_bwd<T, 4><<<nb, 256, lds, s>>>(a); else k_head_fwd<T, 4><<<nb, 256, lds, s>>>(a); break;
+        case 6: if (bwd) k_head_bwd<T, 6><<<nb, 256, lds, s>>>(a); else k_head_fwd<T, 6><<<nb, 256, lds, s>>>(a); break;
+        default: if (bwd) k_head_bwd<T, 8><<<nb, 256, lds, s>>>(a); else k_head_fwd<T, 8><<<nb, 256, lds, s>>>(a); break;
+    }
+}
+static int head_co(int Cout) { return Cout <= 2 ? 2 : Cout <= 4 ? 4 : Cout <= 6 ? 6 : 8; }
+void launch_head_fwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* w, const float* bias, void* y, float* out_ncdhw,
+                     hipStream_t s) {
+    HeadArgs a = {};
+    a.src = src; a.w = w; a.bias = bias; a.Cin = g.Cin; a.Cout = g.Cout; a.lc = ilog2_exact(g.Cin / 16);
+    a.S = (int64_t)g.D * g.H * g.W; a.y = y; a.out = out_ncdhw;
+    const int CO = head_co(g.Cout);
+    int64_t items = ((a.S + 63) & ~(int64_t)63) << a.lc;
+    int64_t nb = (items + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    UNET_DISPATCH(dtype, (head_launch<T>(false, CO, (int)nb, (size_t)CO * g.Cin * 4, a, s)));
+}
+void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* dy_ncdhw, const void* dy_cl, const float* w,
+                     DstGrad dst, float* dw, float* db, void* scratch, hipStream_t s) {
+    HeadArgs a = {};
+    a.src = src; a.w = w; a.Cin = g.Cin; a.Cout = g.Cout; a.lc = ilog2_exact(g.Cin / 16);
+    a.S = (int64_t)g.D * g.H * g.W; a.dy_planes = dy_ncdhw; a.dy_cl = dy_cl; a.dst = dst;
+    a.slab = dw ? (float*)scratch : nullptr;
+    const int CO = head_co(g.Cout);
+    const int nb = wgrad_reg_blocks((a.S << a.lc) * 4);   // one (voxel, chunk) item per thread until 512 blocks are reached
+    const size_t l0 = (size_t)CO * g.Cin * 4, l1 = (size_t)4 * (1 << a.lc) * (CO * 17) * 4;
+    UNET_DISPATCH(dtype, (head_launch<T>(true, CO, nb, l0 > l1 ? l0 : l1, a, s)));
+    if (dw) slab_reduce2(a.slab, nb, (int64_t)g.Cin * g.Cout + g.Cout, dw, (int64_t)g.Cin * g.Cout, db, s);
 }
 
 }  // namespace unet
