@@ -689,7 +689,7 @@ int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, f
         if (!p->segs_dev) throw std::runtime_error("unet_sgd_step: plan was created without a device");
         DeviceGuard dg(p->device);
         hipStream_t s = (hipStream_t)stream;
-        const int nblk = 256;
+        const int nblk = 1024;           // partial sums of squares (scratch: 64 KiB)
         float* partial = (float*)scratch;
         launch_sumsq_partial(grads, p->n_param_elems, grad_scale, partial, nblk, s);
         launch_sgd(params, grads, mom, p->n_param_elems, p->segs_dev, p->nseg, partial, nblk, lr, momentum, nesterov, wd, clip_norm,

@@ -610,16 +610,20 @@ __global__ void __launch_bounds__(256) k_loss_finalize(const float* __restrict__
     extern __shared__ double shd[];  // 3 + 2*oc
     __shared__ double redd[256];
     int np = 3 + 2 * oc;
-    for (int i = 0; i < np; ++i) {   // all 256 threads sum one value's partials, fixed-order tree
+    // 16 values x 16 split lanes per pass (fixed order): one pass for out_count <= 6 instead of np block-wide tree reductions
+    const int vi = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    for (int i0 = 0; i0 < np; i0 += 16) {
+        const int i = i0 + vi;
         double a = 0.0;
-        for (int b = threadIdx.x; b < nblk; b += 256) a += partial[(int64_t)b * np + i];
+        if (i < np)
+            for (int b = ly; b < nblk; b += 16) a += partial[(int64_t)b * np + i];
         redd[threadIdx.x] = a;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) redd[threadIdx.x] += redd[threadIdx.x + o];
-            __syncthreads();
+        if (ly == 0 && i < np) {
+            double t = 0.0;
+            for (int k = 0; k < 16; ++k) t += redd[k * 16 + vi];
+            shd[i] = t;
         }
-        if (threadIdx.x == 0) shd[i] = redd[0];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -712,8 +716,14 @@ __global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__
     double acc = 0.0;
     for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += (int64_t)gridDim.x * 1024) {
         float r = 0.f;
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j < n) { float x = g[i0 + j] * scale; r = fmaf(x, x, r); }
+        if (i0 + 3 < n) {
+            const float4 v = *(const float4*)(g + i0);
+            const float a0 = v.x * scale, a1 = v.y * scale, a2 = v.z * scale, a3 = v.w * scale;
+            r = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, a3 * a3)));
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < n) { float x = g[i0 + j] * scale; r = fmaf(x, x, r); }
+        }
         acc += (double)r;
     }
     red[threadIdx.x] = acc;
@@ -728,39 +738,75 @@ void launch_sumsq_partial(const float* g, int64_t n, float scale, float* partial
     k_sumsq_partial<<<nblk, 256, 0, s>>>(g, n, scale, partial);
 }
 
+// One fused pass: total gradient norm from the partials, clip coefficient, weight decay (per parameter segment), Nesterov
+// momentum, parameter update and zero_grad.  Four consecutive elements per thread (16-B accesses); the segment table and the
+// partials are reduced through LDS once per block.
+constexpr int SGD_MAXSEG = 1024;
 __global__ void __launch_bounds__(256) k_sgd(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, int64_t n,
                                              const SgdSeg* __restrict__ segs, int nseg, const float* __restrict__ partial, int nblk,
                                              float lr, float momentum, int nesterov, float wdecay, float clip_norm, float grad_scale, float* norm_out) {
+    __shared__ double red[256];
     __shared__ float s_coef;
+    __shared__ int64_t s_off[SGD_MAXSEG];
+    __shared__ float s_wd[SGD_MAXSEG];
+    double part = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) part += partial[b];
+    red[threadIdx.x] = part;
+    const int ns = nseg < SGD_MAXSEG ? nseg : SGD_MAXSEG;
+    for (int k = threadIdx.x; k < ns; k += 256) { s_off[k] = segs[k].offset; s_wd[k] = segs[k].wd; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int b = 0; b < nblk; ++b) tot += partial[b];
-        float norm = (float)sqrt(tot);
+        float norm = (float)sqrt(red[0]);
         float coef = clip_norm / (norm + 1e-6f);
         s_coef = coef > 1.f ? 1.f : coef;
         if (blockIdx.x == 0 && norm_out) *norm_out = norm;
     }
     __syncthreads();
-    float coef = s_coef * grad_scale;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float coef = s_coef * grad_scale;
+    auto seg_of = [&](int64_t i) {          // last segment with offset <= i
         int lo = 0, hi = nseg - 1;
-        while (lo < hi) {  // last segment with offset <= i
+        while (lo < hi) {
             int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].offset <= i) lo = mid; else hi = mid - 1;
+            int64_t off = mid < SGD_MAXSEG ? s_off[mid] : segs[mid].offset;
+            if (off <= i) lo = mid; else hi = mid - 1;
         }
-        float wd = segs[lo].wd * wdecay;
-        float pv = p[i];
-        float d = fmaf(wd, pv, g[i] * coef);
-        float b = fmaf(momentum, m[i], d);
-        m[i] = b;
-        p[i] = pv - lr * (nesterov ? fmaf(momentum, b, d) : b);
-        g[i] = 0.f;
+        return lo;
+    };
+    auto wd_of = [&](int sg) { return (sg < SGD_MAXSEG ? s_wd[sg] : segs[sg].wd) * wdecay; };
+    auto upd = [&](float& pv, float& gv, float& mv, float wd) {
+        float d = fmaf(wd, pv, gv * coef);
+        float b = fmaf(momentum, mv, d);
+        mv = b;
+        pv = pv - lr * (nesterov ? fmaf(momentum, b, d) : b);
+        gv = 0.f;
+    };
+    const int64_t n4 = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+        const int64_t i = q * 4;
+        const int sg = seg_of(i);
+        const int64_t next = sg + 1 < nseg ? (sg + 1 < SGD_MAXSEG ? s_off[sg + 1] : segs[sg + 1].offset) : n;
+        float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i);
+        float w0 = wd_of(sg), w1 = w0, w2 = w0, w3 = w0;
+        if (next < i + 4) { w1 = wd_of(seg_of(i + 1)); w2 = wd_of(seg_of(i + 2)); w3 = wd_of(seg_of(i + 3)); }
+        upd(pv.x, gv.x, mv.x, w0); upd(pv.y, gv.y, mv.y, w1); upd(pv.z, gv.z, mv.z, w2); upd(pv.w, gv.w, mv.w, w3);
+        *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(g + i) = gv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float pv = p[i], gv = g[i], mv = m[i];
+        upd(pv, gv, mv, wd_of(seg_of(i)));
+        p[i] = pv; m[i] = mv; g[i] = gv;
     }
 }
 void launch_sgd(float* p, float* g, float* m, int64_t n, const SgdSeg* segs, int nseg, const float* partial, int nblk, float lr,
                 float momentum, int nesterov, float wdecay, float clip_norm, float grad_scale, float* norm_out, hipStream_t s) {
-    int64_t nb = (n + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    int64_t nb = (n / 4 + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
     k_sgd<<<(unsigned)nb, 256, 0, s>>>(p, g, m, n, segs, nseg, partial, nblk, lr, momentum, nesterov, wdecay, clip_norm, grad_scale, norm_out);
 }
 
