@@ -207,7 +207,7 @@ struct unet_plan {
                 jb[k].src_off = p_off[op.weight];
                 jb[k].dst_off = (int64_t)(k == 0 ? wm_fwd[i] : wm_dgrad[i]);
                 jb[k].blk0 = pack_blocks;
-                pack_blocks += (jb[k].total + 255) / 256;
+                pack_blocks += jb[k].total;
                 pack_jobs.push_back(jb[k]);
             }
         }
