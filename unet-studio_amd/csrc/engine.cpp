@@ -297,6 +297,14 @@ struct Exec {
                         // a head: results[level] straight from the source tensor (the channels-last copy only if nobody asked for the level)
                         float* o = outs[op.out_level];
                         launch_head_fwd(p.dtype, cg, sd[0], params[op.weight], params[op.bias], o ? nullptr : tptr(op.dst), o, s);
+                    } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level < 0 &&
+                               conv_first_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
+                        const Tensor& T = g.tensors[op.dst];
+                        bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
+                        int rows = launch_conv_first_mfma(cg, sd, params[op.weight], params[op.bias], tptr(op.dst),
+                                                          want_stats ? partial() : nullptr, s);
+                        if (want_stats) fused_blocks[T.norm] = rows;
+                        if (mode == 1) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                     } else if (op.kind == OP_CONV) {
                         launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
@@ -761,6 +769,8 @@ int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_conv_w(w, wm, nullptr, g, s);
             launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, nullptr, s);
+        } else if (impl == UNET_IMPL_AUTO && conv_first_mfma_supported(dtype, g, &sd, 1)) {
+            launch_conv_first_mfma(g, &sd, w, b, y, nullptr, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
             launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
@@ -783,6 +793,9 @@ int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* sc
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_conv_w(w, wm, nullptr, g, s);
             int rows = launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, stats ? part : nullptr, s);
+            if (stats) launch_stats_sum(part, rows, cout, stats, s);
+        } else if (impl == UNET_IMPL_AUTO && conv_first_mfma_supported(dtype, g, &sd, 1)) {
+            int rows = launch_conv_first_mfma(g, &sd, w, b, y, stats ? part : nullptr, s);
             if (stats) launch_stats_sum(part, rows, cout, stats, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);

@@ -132,6 +132,12 @@ void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgra
 // returns the number of statistics partial rows written to stats_partial ([rows][Cout][2], one per persistent block)
 int launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
                          float* stats_partial, hipStream_t s);
+// the first conv (Cin = 1, 3x3x3 stride 1, Cout 16 or 32, plain bf16 input) on the matrix cores, filter read as fp32 torch layout;
+// returns the number of statistics partial rows (<= conv_first_mfma_blocks)
+bool conv_first_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+int conv_first_mfma_blocks(const ConvGeom& g);
+int launch_conv_first_mfma(const ConvGeom& g, const SrcDesc* src, const float* w, const float* bias, void* out, float* stats_partial,
+                           hipStream_t s);
 // upper bound of that row count (tiles of the geometry): sizes the partials buffer
 int mfma_conv_blocks(const ConvGeom& g);
 // wgrad (+ bias grad) of a 3x3x3 conv, stride 1 or 2; dw/db fp32 torch layout, accumulated (+=); db may be nullptr
