@@ -60,9 +60,14 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
     const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
     const int C0 = a.asrc[0].C;
 
-    f32x4 acc[T];
+    // TS (one pair per block): the 4 waves split the TAPS (wave w owns taps w, w+4, ...) instead of the K-steps: 7 accumulators
+    // instead of 27 leave registers for a 4-deep ring of A fragments -- with 27 accumulators only one tr-read pair could be in
+    // flight per MFMA and the tap loop ran at LDS latency (~100 cycles per 16-cycle MFMA at 2 waves per SIMD).
+    constexpr bool TS = P == 1;
+    constexpr int TW = (T + 3) / 4, NACC = TS ? TW : T;
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
@@ -172,13 +177,57 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
     // PREF: the next tile's global loads ride in registers through the MFMA phase (27 tap accumulators = 108 VGPRs leave room
     // for ~10 staging units per thread); the wider configurations load and store back to back as before.
     constexpr bool PREF = KD == 2 || (S == 1 && PI == 1 && ITERS_A + ITERS_B <= 8);
+    // tap-split MFMA phase of wave W: iterations n = (K-step s, own tap i) fully unrolled, every LDS address = a per-lane base
+    // + a compile-time offset, RD A-fragment read pairs in flight
+    auto ts_phase = [&](auto wc) {
+        constexpr int W = decltype(wc)::value;
+        constexpr int NTW = (T - W + 3) / 4, NIT = KSTEPS * NTW, RD = 4;
+        const int lr = gq / GPR, lxg = gq % GPR;
+        const char* pal = pa + ((lr * S) * HX + (4 * lxg + q4) * S) * 32;
+        const char* pbl = pb + (lr * BX + 4 * lxg + q4) * 32;
+        auto aoff = [](int s, int r, int t) {
+            const int cr = (8 * s + 4 * r) / GPR, z = cr / BY, y = cr % BY;
+            return ((z * S * HY + y * S) * HX) * 32 + (((t / (KD * KD)) * HY + (t / KD) % KD) * HX + t % KD) * 32;
+        };
+        auto boff = [](int s, int r) {
+            const int cr = (8 * s + 4 * r) / GPR, z = cr / BY, y = cr % BY;
+            return ((z * BY + y) * BX) * 32;
+        };
+        bf16x8 ring[RD], bfr[2];
+        bfr[0] = tr_read2(pbl + boff(0, 0), pbl + boff(0, 1));
+#pragma unroll
+        for (int n = 0; n < RD; ++n)
+            if (n < NIT) ring[n] = tr_read2(pal + aoff(n / NTW, 0, W + 4 * (n % NTW)), pal + aoff(n / NTW, 1, W + 4 * (n % NTW)));
+#pragma unroll
+        for (int n = 0; n < NIT; ++n) {
+            const int s = n / NTW, i = n % NTW;
+            if (i == 0 && s + 1 < KSTEPS) bfr[(s + 1) & 1] = tr_read2(pbl + boff(s + 1, 0), pbl + boff(s + 1, 1));
+            __builtin_amdgcn_sched_barrier(0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[n % RD], bfr[s & 1], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n + RD < NIT) {
+                const int m = n + RD;
+                ring[m % RD] = tr_read2(pal + aoff(m / NTW, 0, W + 4 * (m % NTW)), pal + aoff(m / NTW, 1, W + 4 * (m % NTW)));
+            }
+        }
+    };
     if (PREF && (int)blockIdx.x < ntiles) prefetch(blockIdx.x, std::false_type{});
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();                 // every wave is done reading the previous tile
         if constexpr (PREF) commit(); else prefetch(tile, std::true_type{});
         __syncthreads();
         if (PREF && tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x, std::false_type{});   // in flight during the MFMAs below
+        if constexpr (TS) {
+            switch (wave) {
+                case 0: ts_phase(std::integral_constant<int, 0>{}); break;
+                case 1: ts_phase(std::integral_constant<int, 1>{}); break;
+                case 2: ts_phase(std::integral_constant<int, 2>{}); break;
+                default: ts_phase(std::integral_constant<int, 3>{}); break;
+            }
+            continue;
+        }
         // ---- MFMA: this wave's K-steps; the tr-reads of tap t+1 are issued before the MFMA of tap t ----
+        if constexpr (!TS) {
 #pragma unroll 1
         for (int s = kw; s < KSTEPS; s += WPP) {
             int ao[2], bo[2];
@@ -204,8 +253,27 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }
     }
 
+    if constexpr (TS) {
+        // every wave holds finished taps: gather [t][lane][4] in LDS, then each lane's run [r][t] (4*T floats, contiguous in the
+        // slab's gradient layout) goes out as 16-B stores
+        __syncthreads();
+        float* tl = (float*)smem;
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+            if (wave + 4 * i < T) *(f32x4*)(tl + ((wave + 4 * i) * 64 + lane) * 4) = acc[i];
+        __syncthreads();
+        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout + (((size_t)coB * 16 + il) * g.Cin + (size_t)ciB * 16 + gq * 4) * T;
+        for (int e = wave; e < T; e += 4) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = tl[(((4 * e + k) % T) * 64 + lane) * 4 + (4 * e + k) / T];
+            *(f32x4*)(sl + 4 * e) = v;
+        }
+    }
+    if constexpr (!TS) {
     // ---- reduce the K-split waves of each pair through LDS, then write the slab ----
     __syncthreads();
     float* red = (float*)smem;   // [P][T][64][4]
@@ -238,6 +306,7 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
             for (int k = 0; k < 4; ++k) v[k] = acc[(4 * e + k) % T][(4 * e + k) / T];
             *(f32x4*)(sl + 4 * e) = v;
         }
+    }
     }
     if (do_bias) {
         // threads with equal ub hold partial sums of the same 8 channels: reduce over the 256/GB of them
