@@ -69,9 +69,18 @@ struct unet_plan {
     int nseg = 0;
     int64_t n_param_elems = 0;
 
+    // backward side stream: the parameter-gradient kernels (wgrad, its reduce, bias grad) of a layer run beside the
+    // dgrad -> norm-backward chain of the next one (they only share read-only inputs); forked / joined with events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    size_t head_off = 0;                     // scratch of the fused head backward (stays on the main stream)
+
     ~unet_plan() {
         if (segs_dev) (void)hipFree(segs_dev);
         if (jobs_dev) (void)hipFree(jobs_dev);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
     }
 
     ConvGeom op_geom_of(const Op& op) const {
@@ -148,7 +157,7 @@ struct unet_plan {
         partial_off = take(partial_bytes);
         // MFMA wgrad: one shared slab scratch (ops run one after another on the stream)
         wgrad_mfma.assign(g.ops.size(), 0);
-        size_t wmax = 0;
+        size_t wmax = 0, hmax = 0;
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             if (op.kind != OP_CONV || impl != UNET_IMPL_AUTO) continue;
@@ -173,7 +182,7 @@ struct unet_plan {
             }
             if (op.kind == OP_CONV && head_supported(cg, op.nsrc)) {
                 b = head_bwd_scratch_bytes(cg);
-                if (b > wmax) wmax = b;
+                if (b > hmax) hmax = b;
             }
             if (op.kind == OP_CONVT && impl == UNET_IMPL_AUTO) {
                 SrcDesc sd[2];
@@ -188,6 +197,7 @@ struct unet_plan {
             }
         }
         wgrad_off = take(wmax ? wmax : 256);
+        head_off = take(hmax ? hmax : 256);
         ws_bytes = off;
         // batched filter pack: one job per MFMA filter pack, sources as offsets into a flat parameter buffer
         p_off.assign(g.params.size() + 1, 0);
@@ -393,6 +403,15 @@ struct Exec {
             for (int k = 0; k < op.nsrc; ++k)
                 if (g.tensors[op.src[k]].needs_grad) init[op.src[k]] = 1;
         };
+        // sb: where the parameter-gradient kernels go.  fork() orders them after everything issued so far on the caller's stream
+        // (dL/d(raw output) of the layer is final); the join at the end orders the caller's stream after them.
+        static const bool no_side = getenv("UNET_NO_SIDE_STREAM") != nullptr;
+        const hipStream_t sb = (p.side && !no_side) ? p.side : s;
+        auto fork = [&]() {
+            if (sb == s) return;
+            HIP_OK(hipEventRecord(p.ev_fork, s));
+            HIP_OK(hipStreamWaitEvent(sb, p.ev_fork, 0));
+        };
         for (int i = (int)g.ops.size() - 1; i >= 0; --i) {
             const Op& op = g.ops[i];
             if (op.kind == OP_NORM) continue;
@@ -410,7 +429,7 @@ struct Exec {
                     // fused head backward: dL/dW, dL/db and dL/d(source view) in one pass over (source, dL/dresults[level])
                     DstGrad dgh = dst_of(op.src[0]);
                     launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
-                                    gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                                    gparams[op.weight], gparams[op.bias], ws + p.head_off, s);
                     if (dgh.ptr) mark(op);
                     continue;
                 }
@@ -427,21 +446,22 @@ struct Exec {
                     ConvGeom cg = geom(op);
                     const float* wd = (const float*)(ws + p.w_dgrad[i]);
                     bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
+                    fork();
                     if (op.kind == OP_CONV) {
                         if (p.wgrad_mfma[i])
-                            launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                            launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
-                            launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                            launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else
-                            launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                            launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         if (any && p.dgrad_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
                         if (p.wgrad_mfma[i]) {
-                            launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + p.wgrad_off, s);
-                            launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, s);
+                            launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + p.wgrad_off, sb);
+                            launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
                         } else {
-                            launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, s);
+                            launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         }
                         if (any && p.dgrad_mfma[i]) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
@@ -475,6 +495,10 @@ struct Exec {
                     break;
                 default: break;
             }
+        }
+        if (sb != s) {   // join: whatever the caller enqueues next (optimizer step, next forward) sees every gradient
+            HIP_OK(hipEventRecord(p.ev_join, sb));
+            HIP_OK(hipStreamWaitEvent(s, p.ev_join, 0));
         }
     }
 };
@@ -551,6 +575,11 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
         int nd = 0;
         if (hipGetDeviceCount(&nd) == hipSuccess && nd > 0) {
             DeviceGuard dg(device);
+            int pr_least = 0, pr_greatest = 0;   // the side stream yields to the caller's (critical-path) stream
+            (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+            HIP_OK(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, pr_least));
+            HIP_OK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            HIP_OK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
             HIP_OK(hipMalloc((void**)&p->segs_dev, segs.size() * sizeof(SgdSeg)));
             HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
             if (!p->pack_jobs.empty()) {
