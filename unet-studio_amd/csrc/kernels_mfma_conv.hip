@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_mfma(ConvFirstArgs a) {
 // ---- launch plumbing ----
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
 static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns gridDim.x = the number of statistics partial rows
-    constexpr int NW = (BZ * BY * BX / 16) % 8 == 0 && BZ * BY * BX >= 256 ? 8 : 4;   // waves per block
+    constexpr int NW = 4;   // waves per block (8-wave blocks under a 128-VGPR cap measured no faster once the kernels stopped spilling)
     MfmaConvArgs a = a0;
     a.tiles_x = (a.g.Wo + BX - 1) / BX; a.tiles_y = (a.g.Ho + BY - 1) / BY; a.tiles_z = (a.g.Do + BZ - 1) / BZ;
     constexpr bool SWZ = CK == 32 && S == 1 && KD == 3;
@@ -819,7 +819,7 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if constexpr (NW == 8 && NT == 1 && !SC) {
+    if constexpr (NT == 1 && !SC) {
         // single-chunk layers (Cin == CK: 32->16 and 16->16 at 128^3): 4-wave blocks, <= 256 VGPRs, no spills
         // (measured against the 8-wave / 128-VGPR form: 0.087 -> 0.082 ms on the dominant layer, 4.16 -> 4.09 ms per step)
         if (a.g.Cin == CK) {
