@@ -27,7 +27,7 @@ PEAK_F32_MATRIX = 157.3e12
 PEAK_HBM = 8.0e12
 
 
-def dominant_kernel(U, size, dtype_name, iters=10):
+def dominant_kernel(U, size, dtype_name, iters=20):
     """Times the heaviest conv3d of the step (decode0.0: 32->16 @ size^3, 3x3x3) as launched through the C ABI.
     Returns (algorithmic flops per launch, avg seconds per launch)."""
     import ctypes as C
@@ -54,7 +54,8 @@ def dominant_kernel(U, size, dtype_name, iters=10):
     def run():
         E.check(E.lib.unet_op_conv3d_fwd_packed(edt, x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), sc.data_ptr(),
                                                 cin, cout, D, H, W, 3, 1, st))
-    run(); run()
+    for _ in range(10):
+        run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -18,6 +18,7 @@
 //   * epilogue: + bias, round to bf16, 8-B stores (4 consecutive channels per lane); optional per-block
 //     {sum, sum of squares} per channel for the following norm; optional accumulate / two destinations (dgrad
 //     of a concat); SC = depth-to-space scatter: row block `tap` goes to output voxel 2*v + tap.
+#include <type_traits>
 #include "mfma_util.h"
 
 namespace unet {
@@ -791,6 +792,213 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_mfma(ConvFirstArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sliding-window form for the single-chunk 3x3x3 stride-1 layers with 32 contraction channels (32->16 at 128^3, the 32->32
+// layers at 64^3 and their dgrads).  k_mfma_conv_p stages a 6x6x18 halo (41 KB) per 256 output voxels: 2.5x more LDS writes and
+// L2 reads than outputs, and LDS stores run at ~79 B/clk/CU -- as long as the tile's MFMAs.  Here a block owns an 8x16 (y,x)
+// footprint and walks z: each step stages ONE 10x18 plane (11.5 KB for 128 outputs, 1.4x) into a ring of four planes while it
+// computes the output plane whose three input planes are already resident -- one barrier per plane, the stores of plane p+1
+// overlap the MFMAs of plane p-1.  Same packed filter, arguments, epilogue semantics and statistics rows (one per
+// blockIdx.x) as k_mfma_conv_p<1,3,1,..,32,1,false>.
+// ------------------------------------------------------------------------------------------------
+struct ZWork { int nseg, zlen, cols_x, cols_y; };
+__global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw) {
+    constexpr int BY = 8, BX = 16, HY = BY + 2, HX = BX + 2, HXP = 20, PLANE_B = HY * HXP * 64, RING = 4;
+    constexpr int UNITS = HY * HX * 4, ITERS = (UNITS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4, lg = tid & 3;
+    const int nt0 = blockIdx.y, NTT = g.Cout / 16, C0 = a.src[0].C;
+    const bf16x8* wp = (const bf16x8*)a.w;
+
+    // the (only) chunk's 27 filter fragments live in registers for the whole block (108 VGPRs; the plane ring needs few staging
+    // registers, unlike the halo tiles of k_mfma_conv_p): the tap loop reads only patches from LDS, 1 KB per MFMA instead of 1.5
+    bf16x8 wf[27];
+#pragma unroll
+    for (int ks = 0; ks < 27; ++ks) wf[ks] = wp[((size_t)ks * NTT + nt0) * 64 + lane];
+    // this lane's patch addresses inside a plane for its two m-tiles (rows 2*wave, 2*wave + 1), per kx (swizzled as in k_mfma_conv_p)
+    int mbase[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hx = j + kx;
+            mbase[i][kx] = ((2 * wave + i) * HXP + hx) * 64 + ((gq ^ (((hx >> 2) & 1) << 1)) << 4);
+        }
+    // staging units of a plane
+    int ulds[ITERS], uyx[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int u = tid + it * 256, hv = u >> 2, hy = hv / HX, hx = hv % HX;
+        ulds[it] = u < UNITS ? (hy * HXP + hx) * 64 + ((lg ^ (((hx >> 2) & 1) << 1)) << 4) : -1;
+        uyx[it] = hy | (hx << 8);
+    }
+    const int c = lg * 8, sidx = (a.nsrc > 1 && c >= C0) ? 1 : 0;
+    const char* sptr = (const char*)(sidx ? a.src[1].ptr : a.src[0].ptr) + (size_t)(c - (sidx ? C0 : 0)) * 2;
+    const int sC = sidx ? a.src[1].C : C0;
+    const unsigned vstride = (unsigned)sC * 2;
+
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int cch = nt0 * 16 + gq * 4;                         // this lane's 4 output channels
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b4[r] = a.bias[cch + r];
+    }
+    const int dsel = (a.nout > 1 && cch >= a.outC[0]) ? 1 : 0;
+    const int cd = cch - (dsel ? a.outC[0] : 0);
+    char* obase = (char*)(dsel ? a.out[1] : a.out[0]);
+    const int oC = dsel ? a.outC[1] : a.outC[0], oacc = dsel ? a.out_acc[1] : a.out_acc[0];
+
+    const int nitems = zw.cols_x * zw.cols_y * zw.nseg;
+    bf16x8 R[ITERS];
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int seg = item % zw.nseg, col = item / zw.nseg;
+        const int x0 = (col % zw.cols_x) * BX, y0 = (col / zw.cols_x) * BY;
+        const int zs = seg * zw.zlen, ze = zs + zw.zlen < g.D ? zs + zw.zlen : g.D;      // output planes [zs, ze)
+        // per-column constants: which staging units lie inside the volume (y, x) and their address in plane 0 of the column
+        unsigned umask = 0;
+        const char* ubase[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int gy = y0 - 1 + (uyx[it] & 255), gx = x0 - 1 + (uyx[it] >> 8);
+            const bool ok = ulds[it] >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            if (ok) umask |= 1u << it;
+            ubase[it] = sptr + (size_t)(ok ? gy * g.W + gx : 0) * vstride;
+        }
+        const size_t plane_bytes = (size_t)g.H * g.W * vstride;
+        auto prefetch = [&](int pz, bf16x8 (&Rr)[ITERS]) {
+            const bool zin = (unsigned)pz < (unsigned)g.D;
+            const size_t po = (size_t)(zin ? pz : 0) * plane_bytes;      // uniform
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                Rr[it] = zero8;
+                if (zin && ((umask >> it) & 1u)) Rr[it] = *(const bf16x8*)(ubase[it] + po);
+            }
+        };
+        // output pointers of this lane's two voxels, plane zs; advanced by one plane per step
+        const int oy[2] = {y0 + 2 * wave, y0 + 2 * wave + 1}, ox = x0 + j;
+        const bool ook[2] = {oy[0] < a.oH && ox < a.oW && obase != nullptr, oy[1] < a.oH && ox < a.oW && obase != nullptr};
+        char* optr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) optr[i] = obase + ((((size_t)zs * a.oH + (ook[i] ? oy[i] : 0)) * a.oW + (ook[i] ? ox : 0)) * oC + cd) * 2;
+        const size_t oplane = (size_t)a.oH * a.oW * oC * 2;
+
+        // one output plane; SL = slot of input plane z-1 (compile-time: every LDS address is a per-lane base + an immediate)
+        auto plane = [&](auto slc) {
+            constexpr int SL = decltype(slc)::value;
+            constexpr int PD = 2;              // taps in flight ahead of the MFMAs
+            f32x4 acc[2];
+            bf16x8 xbuf[PD + 1][2];
+            auto load_tap = [&](int ks, int sl) {
+                const int kz = ks / 9, ky = (ks / 3) % 3, kx = ks % 3;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    xbuf[sl][i] = *(const bf16x8*)(smem + mbase[i][kx] + ((SL + kz) & 3) * PLANE_B + ky * HXP * 64);
+            };
+#pragma unroll
+            for (int k0 = 0; k0 < PD; ++k0) load_tap(k0, k0);
+#pragma unroll
+            for (int ks = 0; ks < 27; ++ks) {
+                if (ks + PD < 27) load_tap(ks + PD, (ks + PD) % (PD + 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], xbuf[ks % (PD + 1)][i], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (ook[i]) {
+                    uint2* p = (uint2*)optr[i];
+                    float v0 = acc[i][0] + b4[0], v1 = acc[i][1] + b4[1], v2 = acc[i][2] + b4[2], v3 = acc[i][3] + b4[3];
+                    if (oacc) {
+                        const uint2 old = *p;
+                        v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                    *p = o;
+                    if (a.stats) {
+                        const float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
+                        s1[0] += r0; s1[1] += r1; s1[2] += r2; s1[3] += r3;
+                        s2[0] = fmaf(r0, r0, s2[0]); s2[1] = fmaf(r1, r1, s2[1]); s2[2] = fmaf(r2, r2, s2[2]); s2[3] = fmaf(r3, r3, s2[3]);
+                    }
+                }
+                optr[i] += oplane;
+            }
+        };
+
+        // (measured: issuing the load of plane pz+2 instead of pz+1 -- two planes of latency ahead, two copies of the step --
+        //  was slower, 0.064 -> 0.076 ms on the 32->16 layer)
+        __syncthreads();                       // previous item's planes are no longer read
+        prefetch(zs - 1, R);
+        for (int pz = zs - 1; pz <= ze; ++pz) {
+            const int slot = (pz + 1) & 3;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                if (ulds[it] >= 0) *(bf16x8*)(smem + slot * PLANE_B + ulds[it]) = R[it];
+            if (pz + 1 <= ze) prefetch(pz + 1, R);
+            __syncthreads();
+            if (pz < zs + 1) continue;
+            // output plane z = pz-1: its input planes z-1, z, z+1 are resident; slot(z-1) = z & 3
+            switch ((pz - 1) & 3) {
+                case 0: plane(std::integral_constant<int, 0>{}); break;
+                case 1: plane(std::integral_constant<int, 1>{}); break;
+                case 2: plane(std::integral_constant<int, 2>{}); break;
+                default: plane(std::integral_constant<int, 3>{}); break;
+            }
+        }
+    }
+    if (a.stats) {
+        float* red = (float*)smem;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float u = s1[r], v = s2[r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+            if (j == 0) { red[(wave * 16 + gq * 4 + r) * 2] = u; red[(wave * 16 + gq * 4 + r) * 2 + 1] = v; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { u += red[(w * 16 + tid) * 2]; v += red[(w * 16 + tid) * 2 + 1]; }
+            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 0] = u;
+            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 1] = v;
+        }
+    }
+}
+// sliding-window launcher: returns 0 if the geometry does not qualify, else gridDim.x
+static int launch_conv_z(const MfmaConvArgs& a0, hipStream_t s) {
+    const ConvGeom& g = a0.g;
+    static const bool off = getenv("UNET_NO_CONV_Z") != nullptr;
+    if (off || g.Cin != 32 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
+    ZWork zw;
+    zw.cols_x = (g.Wo + 15) / 16; zw.cols_y = (g.Ho + 7) / 8;
+    const int cols = zw.cols_x * zw.cols_y, gy = g.Cout / 16;
+    int want = 512 / gy;                               // two blocks per CU in total
+    if (want < 1) want = 1;
+    int nseg = (want + cols - 1) / cols;               // z segments per column so that items >= the wanted block count
+    if (nseg < 1) nseg = 1;
+    int zlen = (g.Do + nseg - 1) / nseg;
+    if (zlen < 4) zlen = 4;                            // at least 4 output planes per 2 warm-up planes
+    nseg = (g.Do + zlen - 1) / zlen;
+    zw.nseg = nseg; zw.zlen = zlen;
+    const int items = cols * nseg;
+    const int gx = items < want ? items : want;
+    constexpr int lds = 4 * 10 * 20 * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_mfma_conv_z, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    k_mfma_conv_z<<<dim3((unsigned)gx, (unsigned)gy), 256, lds, s>>>(a0, zw);
+    return gx;
+}
+
 // ---- launch plumbing ----
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
 static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns gridDim.x = the number of statistics partial rows
@@ -886,6 +1094,7 @@ template <int BZ, int BY, int BX> static int launch_small(const MfmaConvArgs& a0
     return tiles;
 }
 static int launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
+    if (CK == 32) { const int gz = launch_conv_z(a, s); if (gz) return gz; }
     Tile t = tile_s1k3(a.g, CK);
     if (CK == 32 && small_s1k3(a.g, CK)) return t.bx == 8 ? launch_small<2, 4, 8>(a, s) : launch_small<4, 4, 4>(a, s);
     if (t.bx == 16 && t.bz == 4) { if (CK == 32) return launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }
