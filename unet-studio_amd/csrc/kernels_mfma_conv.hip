@@ -1002,7 +1002,9 @@ static int launch_conv_z(const MfmaConvArgs& a0, hipStream_t s) {
 // ---- launch plumbing ----
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, int NT, bool SC>
 static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns gridDim.x = the number of statistics partial rows
-    constexpr int NW = 4;   // waves per block (8-wave blocks under a 128-VGPR cap measured no faster once the kernels stopped spilling)
+    // waves per block: 8 on the larger tiles when a wave then still owns >= 2 row tiles or the kind scatters (measured per variant:
+    // 16->32 dgrad at 128^3 0.085 ms with 8 waves, 0.150 with 4); the one-row-tile kinds run 4 waves without the 128-VGPR cap
+    constexpr int NW = ((BZ * BY * BX / 16) % 8 == 0 && BZ * BY * BX >= 256 && (NT > 1 || SC)) ? 8 : 4;
     MfmaConvArgs a = a0;
     a.tiles_x = (a.g.Wo + BX - 1) / BX; a.tiles_y = (a.g.Ho + BY - 1) / BY; a.tiles_z = (a.g.Do + BZ - 1) / BZ;
     constexpr bool SWZ = CK == 32 && S == 1 && KD == 3;
