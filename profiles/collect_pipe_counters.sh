@@ -17,7 +17,7 @@ R, TAG = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list)
 for f in glob.glob("%s/gpurun_out/pmc_%s_*/*/*counter_collection.csv" % (R, TAG)):
     for r in csv.DictReader(open(f)):
-        if "k_mfma_conv_p" in r["Kernel_Name"]:
+        if "k_mfma_conv_z" in r["Kernel_Name"] or "k_mfma_conv_p" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     print("%-28s %16.0f  (n=%d)" % (k, sum(acc[k]) / len(acc[k]), len(acc[k])))
