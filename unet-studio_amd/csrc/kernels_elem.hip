@@ -548,7 +548,8 @@ __global__ void __launch_bounds__(256) k_loss_partial(const float* __restrict__ 
 template <int OCMAX>
 __global__ void __launch_bounds__(256) k_loss_partial_reg(const float* __restrict__ logits, const int64_t* __restrict__ target, int C,
                                                           int64_t S, int k, float* __restrict__ partial) {
-    __shared__ float red[256];
+    constexpr int RS = 3 + 2 * OCMAX + 1;   // LDS row per wave
+    __shared__ float red[4 * RS];
     const int oc = k ? C - k + 1 : C, np = 3 + 2 * oc;
     float ce = 0.f, mse = 0.f, nv = 0.f, inter[OCMAX], card[OCMAX];
 #pragma unroll
@@ -579,22 +580,22 @@ __global__ void __launch_bounds__(256) k_loss_partial_reg(const float* __restric
         mse += psq - 2.f * pt + 1.f;
         nv += 1.f;
     }
-    for (int i = 0; i < np; ++i) {
-        float val = i == 0 ? ce : i == 1 ? mse : i == 2 ? nv : 0.f;
+    // block sums: xor-shuffles inside a wave, then the 4 wave results through LDS (one barrier; the np block-wide tree reductions
+    // of the first version were 120 barriers per block -- the whole cost of the kernel on the small levels)
+    auto wsum = [](float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w3[3] = {wsum(ce), wsum(mse), wsum(nv)};
+    if (lane == 0) { red[wave * RS + 0] = w3[0]; red[wave * RS + 1] = w3[1]; red[wave * RS + 2] = w3[2]; }
 #pragma unroll
-        for (int c = 0; c < OCMAX; ++c) {
-            if (c < oc && i == 3 + c) val = inter[c];
-            if (c < oc && i == 3 + oc + c) val = card[c];
+    for (int c = 0; c < OCMAX; ++c) {
+        if (c < oc) {
+            const float a = wsum(inter[c]), b = wsum(card[c]);
+            if (lane == 0) { red[wave * RS + 3 + c] = a; red[wave * RS + 3 + oc + c] = b; }
         }
-        red[threadIdx.x] = val;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * np + i] = red[0];
-        __syncthreads();
     }
+    __syncthreads();
+    if ((int)threadIdx.x < np)
+        partial[(int64_t)blockIdx.x * np + threadIdx.x] = red[threadIdx.x] + red[RS + threadIdx.x] + red[2 * RS + threadIdx.x] + red[3 * RS + threadIdx.x];
 }
 void launch_loss_partial(const float* logits, const int64_t* target, int C, int64_t S, int collapse, float* partial, hipStream_t s) {
     int oc = collapse ? C - collapse + 1 : C;
