@@ -670,43 +670,6 @@ __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ log
     float sum = 0.f;
     for (int c = 0; c < oc; ++c) sum += expf(L.get(c) - mx);
     float inv = 1.f / sum;
-    if (oc <= 8) {   // the usual case: softmax, dprob and dlogit of the voxel stay in registers (one exp per class instead of three)
-        float q[8], gq[8];
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            q[c] = 0.f; gq[c] = 0.f;
-            if (c < oc) {
-                q[c] = expf(L.get(c) - mx) * inv;
-                const float p = clamp_p(q[c]);
-                float gg = w_mse * (2.f * p - (c == tt ? 2.f : 0.f)) / n;
-                if (c >= 1) {
-                    const float m = c == tt ? 1.f : 0.f, den = card[c] + eps;
-                    gg += w_dice * (-(2.f * m * den - (2.f * inter[c] + eps)) / (den * den)) / dden;
-                }
-                if (!(q[c] >= 1e-6f && q[c] <= 1.0f - 1e-6f)) gg = 0.f;
-                gq[c] = gg;
-                dot = fmaf(gg, q[c], dot);
-            }
-        }
-        float d0 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c < oc) {
-                const float dl = q[c] * (gq[c] - dot) + w_ce * (q[c] - (c == tt ? 1.f : 0.f)) / n;
-                if (k && c == 0) d0 = dl;
-                else dlogits[(int64_t)(k ? c + k - 1 : c) * S + v] = dl;
-            }
-        }
-        if (k) {
-            float m0 = -INFINITY;
-            for (int c = 0; c < k; ++c) m0 = fmaxf(m0, logits[(int64_t)c * S + v]);
-            float s0 = 0.f;
-            for (int c = 0; c < k; ++c) s0 += expf(logits[(int64_t)c * S + v] - m0);
-            for (int c = 0; c < k; ++c) dlogits[(int64_t)c * S + v] = d0 * expf(logits[(int64_t)c * S + v] - m0) / s0;
-        }
-        return;
-    }
     // pass A: dot = sum_c dprob_c * q_c
     float dot = 0.f;
     for (int c = 0; c < oc; ++c) {
