@@ -84,7 +84,11 @@ int unet_forward(const unet_plan* plan, const float* const* params, float* const
 
 /* backward of the last mode-1 forward on this workspace.  grad_outs: fp32 dL/d(outs[l]) or NULL (= no
  * loss on that level).  grad_params: fp32, parameters() order, ACCUMULATED (+=) as .grad is across the
- * batch_size micro-steps of one optimizer step (train.cpp:604-606,706).  grad_x: optional fp32 dL/dx. */
+ * batch_size micro-steps of one optimizer step (train.cpp:604-606,706).  grad_x: optional fp32 dL/dx.
+ * The parameter-gradient kernels run on a side stream the plan owns, forked from and joined back into `stream`
+ * before the call returns its work to the caller: stream order is all a caller needs, but two host threads must
+ * not run unet_backward on the SAME plan concurrently (the reference trains one model per thread, train.cpp:573-579;
+ * unet_forward stays re-entrant per workspace, qc.cpp:273-297). */
 int unet_backward(const unet_plan* plan, const float* const* params, const float* const* grad_outs,
                   float* const* grad_params, float* grad_x, void* workspace, void* stream);
 
