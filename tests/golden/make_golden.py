@@ -78,6 +78,15 @@ def small_case(name, arch, cin, cout, n, lr=0.01, batch_size=1):
     print(name, "loss", d["loss"], "stats", d["stats"], "gnorm", d["grad_norm"])
 
 
+def logit_stride(n, level):
+    """sampling stride of the stored logits of a level (full tensors are kept up to 16^3 voxels; the L2 norm covers the rest)"""
+    side = n >> level
+    st = 1
+    while side // st > 16:
+        st *= 2
+    return st if n > 64 else (4 if level == 0 else 1)
+
+
 def default_case(n=64):
     """default architecture (train.cpp:1054-1069), in=1, out=6, weights = module init under manual_seed(0)
     (as the GUI does, mainwindow_training.cpp:253).  Params are 60 MB, so the fixture holds a param checksum,
@@ -94,7 +103,8 @@ def default_case(n=64):
     d["param_head"] = np.array([float(p.detach().flatten()[0]) for p in m.parameters()])
     for k, o in enumerate(outs):
         a = o[0].detach().numpy()
-        d["logits%d" % k] = a[:, ::4, ::4, ::4].copy() if k == 0 else a
+        st = logit_stride(n, k)
+        d["logits%d" % k] = a[:, ::st, ::st, ::st].copy()
         d["logits_l2_%d" % k] = float(np.sqrt((a.astype(np.float64) ** 2).sum()))
     d["grad_l2"] = np.array([float(p.grad.double().norm()) for p in m.parameters()])
     d["grad_head"] = np.stack([np.pad(p.grad.flatten()[:16].numpy(), (0, max(0, 16 - p.numel()))) for p in m.parameters()])
@@ -108,3 +118,4 @@ if __name__ == "__main__":
     small_case("mix_16", ARCH_MIX, 2, 3, 16)
     small_case("c16_24", ARCH_16, 1, 4, 24, batch_size=2)
     default_case(64)
+    default_case(128)   # BASELINE.json's size (config 2: the fp32 parity configuration); ~1 min, ~12 GB

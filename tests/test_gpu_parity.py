@@ -263,9 +263,18 @@ def test_network_against_golden(golden_dir, name, dt):
         assert rel(m.forward(x)[0][0].cpu().numpy(), d["infer_logits0"]) < tol
 
 
-def test_default_arch_64_fp32_against_golden(golden_dir):
-    """default architecture (train.cpp:1054-1069) at 64^3, weights = ATen module init under manual_seed(0)"""
-    d = np.load(os.path.join(golden_dir, "default_arch_64.npz"))
+def _logit_stride(n, level):   # = tests/golden/make_golden.py:logit_stride
+    side, st = n >> level, 1
+    while side // st > 16:
+        st *= 2
+    return st if n > 64 else (4 if level == 0 else 1)
+
+
+@pytest.mark.parametrize("size", [64, 128])
+def test_default_arch_fp32_against_golden(golden_dir, size):
+    """default architecture (train.cpp:1054-1069) at 64^3 and at BASELINE.json's 128^3 (config 2, the fp32 parity
+    configuration: logits within 1e-4 relative of the CPU reference), weights = ATen module init under manual_seed(0)"""
+    d = np.load(os.path.join(golden_dir, "default_arch_%d.npz" % size))
     n = int(d["n"])
     torch.manual_seed(0)
     ref = A.UNet3dRef(1, 6, A.default_feature(6))
@@ -280,8 +289,8 @@ def test_default_arch_64_fp32_against_golden(golden_dir):
     outs = m._run_forward(plan, ws, x, 1)
     for k in range(5):
         a = outs[k][0].cpu().numpy()
-        a_s = a[:, ::4, ::4, ::4] if k == 0 else a
-        assert rel(a_s, d["logits%d" % k]) < 1e-4, "logits level %d" % k
+        st = _logit_stride(n, k)
+        assert rel(a[:, ::st, ::st, ::st], d["logits%d" % k]) < 1e-4, "logits level %d" % k
         assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - float(d["logits_l2_%d" % k])) < 1e-4 * float(d["logits_l2_%d" % k])
     losses, gouts = m.loss(outs, t)
     assert abs(float(losses[0]) - float(d["loss"])) < 1e-4 * float(d["loss"])
@@ -291,6 +300,32 @@ def test_default_arch_64_fp32_against_golden(golden_dir):
     assert np.allclose(gl2[big], d["grad_l2"][big], rtol=2e-3)
     heads = np.stack([np.pad(g.flatten()[:16].cpu().numpy(), (0, max(0, 16 - g.numel()))) for g in m.grads()])
     assert rel(heads[big], d["grad_head"][big]) < 2e-3
+
+
+def test_default_arch_128_bf16_against_golden(golden_dir):
+    """the benchmarked configuration itself (bf16 activations, fp32 master weights, default arch, 128^3) against the CPU
+    reference's fixture: logits, loss and the large gradients within the bf16 engine's measured error (bounds as in DESIGN.md 5)"""
+    d = np.load(os.path.join(golden_dir, "default_arch_128.npz"))
+    n = int(d["n"])
+    torch.manual_seed(0)
+    ref = A.UNet3dRef(1, 6, A.default_feature(6))
+    m = U.UNet3d(1, 6, A.default_feature(6), device=DEV, dtype="bf16")
+    m.load_parameters([p.detach().numpy() for p in ref.parameters()])
+    x, t = A.synthetic_sample(1, 6, (n, n, n), 1)
+    x, t = x.to(DEV), t.to(DEV)
+    plan = m.plan_for(x.shape[2:]); ws = m._workspace(plan)
+    outs = m._run_forward(plan, ws, x, 1)
+    for k in range(5):
+        a = outs[k][0].cpu().numpy()
+        st = _logit_stride(n, k)
+        # bf16 rounding noise grows with depth: the 8^3 / 4^3 levels normalise over 512 / 64 voxels only (measured 4.8e-2 at level 4)
+        assert rel(a[:, ::st, ::st, ::st], d["logits%d" % k]) < (4e-2 if k < 3 else 8e-2), "logits level %d" % k
+    losses, gouts = m.loss(outs, t)
+    assert abs(float(losses[0]) - float(d["loss"])) < 1e-2 * float(d["loss"])
+    m._run_backward(plan, ws, gouts)
+    gl2 = np.array([float(g.double().norm()) for g in m.grads()])
+    big = d["grad_l2"] > 1e-2 * d["grad_l2"].max()
+    assert np.allclose(gl2[big], d["grad_l2"][big], rtol=8e-2)
 
 
 @pytest.mark.parametrize("collapse", [0, 2])
