@@ -466,6 +466,8 @@ void launch_materialize_bwd(int dtype, const void* gout, const DstGrad* dst, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// (exp / log are the hardware v_exp_f32 / v_log_f32 forms (__expf, __logf, ~2 ulp): the loss kernels were bound by the precise
+// library versions, 18 exps per voxel; the 1e-4 loss parity and the gradient checks against the oracle hold, tests/test_gpu_parity.py)
 // losses: calc_losses (train.cpp:501-552) over fp32 NCDHW logits and int64 targets
 // ------------------------------------------------------------------------------------------------
 // deep-supervision target pyramid, train.cpp:645-662: nearest, src = min(floor(dst * in/out), in-1)
@@ -501,8 +503,8 @@ __device__ __forceinline__ VoxelLogits make_vl(const float* logits, int64_t S, i
         float mx = -INFINITY;
         for (int c = 0; c < k; ++c) mx = fmaxf(mx, logits[(int64_t)c * S + v]);
         float s = 0.f;
-        for (int c = 0; c < k; ++c) s += expf(logits[(int64_t)c * S + v] - mx);
-        L.lse0 = mx + logf(s);
+        for (int c = 0; c < k; ++c) s += __expf(logits[(int64_t)c * S + v] - mx);
+        L.lse0 = mx + __logf(s);
     }
     return L;
 }
@@ -526,16 +528,16 @@ __global__ void __launch_bounds__(256) k_loss_partial(const float* __restrict__ 
         float mx = -INFINITY;
         for (int c = 0; c < oc; ++c) mx = fmaxf(mx, L.get(c));
         float sum = 0.f;
-        for (int c = 0; c < oc; ++c) sum += expf(L.get(c) - mx);
+        for (int c = 0; c < oc; ++c) sum += __expf(L.get(c) - mx);
         float inv = 1.f / sum, psq = 0.f, pt = 0.f;
         for (int c = 0; c < oc; ++c) {
-            float p = clamp_p(expf(L.get(c) - mx) * inv);
+            float p = clamp_p(__expf(L.get(c) - mx) * inv);
             psq = fmaf(p, p, psq);
             if (c == tt) pt = p;
             if (c >= 1) atomicAdd(&sh[3 + oc + c], p + (c == tt ? 1.f : 0.f));
         }
         if (tt >= 1) atomicAdd(&sh[3 + tt], pt);
-        ce += -(L.get(tt) - mx - logf(sum));
+        ce += -(L.get(tt) - mx - __logf(sum));
         mse += psq - 2.f * pt + 1.f;
         nv += 1.f;
     }
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(256) k_loss_partial_reg(const float* __restric
         for (int c = 0; c < OCMAX; ++c) { lg[c] = c < oc ? L.get(c) : -INFINITY; mx = fmaxf(mx, lg[c]); }
         float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < OCMAX; ++c) { lg[c] = c < oc ? expf(lg[c] - mx) : 0.f; sum += lg[c]; }
+        for (int c = 0; c < OCMAX; ++c) { lg[c] = c < oc ? __expf(lg[c] - mx) : 0.f; sum += lg[c]; }
         float inv = 1.f / sum, psq = 0.f, pt = 0.f, lt = 0.f;
 #pragma unroll
         for (int c = 0; c < OCMAX; ++c) {
@@ -576,7 +578,7 @@ __global__ void __launch_bounds__(256) k_loss_partial_reg(const float* __restric
                 card[c] += p + (hit ? 1.f : 0.f);
             }
         }
-        ce += -(lt - mx - logf(sum));
+        ce += -(lt - mx - __logf(sum));
         mse += psq - 2.f * pt + 1.f;
         nv += 1.f;
     }
@@ -668,12 +670,12 @@ __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ log
     float mx = -INFINITY;
     for (int c = 0; c < oc; ++c) mx = fmaxf(mx, L.get(c));
     float sum = 0.f;
-    for (int c = 0; c < oc; ++c) sum += expf(L.get(c) - mx);
+    for (int c = 0; c < oc; ++c) sum += __expf(L.get(c) - mx);
     float inv = 1.f / sum;
     // pass A: dot = sum_c dprob_c * q_c
     float dot = 0.f;
     for (int c = 0; c < oc; ++c) {
-        float q = expf(L.get(c) - mx) * inv, p = clamp_p(q), g = 0.f;
+        float q = __expf(L.get(c) - mx) * inv, p = clamp_p(q), g = 0.f;
         g += w_mse * (2.f * p - (c == tt ? 2.f : 0.f)) / n;
         if (c >= 1) {
             float m = c == tt ? 1.f : 0.f, den = card[c] + eps;
@@ -685,7 +687,7 @@ __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ log
     // pass B: dlogit_c = q_c*(dprob_c - dot) + w_ce*(q_c - [c==t])/n
     float d0 = 0.f;
     for (int c = 0; c < oc; ++c) {
-        float q = expf(L.get(c) - mx) * inv, p = clamp_p(q), g = 0.f;
+        float q = __expf(L.get(c) - mx) * inv, p = clamp_p(q), g = 0.f;
         g += w_mse * (2.f * p - (c == tt ? 2.f : 0.f)) / n;
         if (c >= 1) {
             float m = c == tt ? 1.f : 0.f, den = card[c] + eps;
@@ -700,8 +702,8 @@ __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ log
         float m0 = -INFINITY;
         for (int c = 0; c < k; ++c) m0 = fmaxf(m0, logits[(int64_t)c * S + v]);
         float s0 = 0.f;
-        for (int c = 0; c < k; ++c) s0 += expf(logits[(int64_t)c * S + v] - m0);
-        for (int c = 0; c < k; ++c) dlogits[(int64_t)c * S + v] = d0 * expf(logits[(int64_t)c * S + v] - m0) / s0;
+        for (int c = 0; c < k; ++c) s0 += __expf(logits[(int64_t)c * S + v] - m0);
+        for (int c = 0; c < k; ++c) dlogits[(int64_t)c * S + v] = d0 * __expf(logits[(int64_t)c * S + v] - m0) / s0;
     }
 }
 void launch_loss_grad(const float* logits, const int64_t* target, int C, int64_t S, int collapse, const float* level_out, float weight,
