@@ -1,0 +1,64 @@
+"""GPU, world_size 2: the data-parallel step of unet-studio_amd/train.py on the real engine.  Both ranks share the one GPU of
+the test box (the collective runs over gloo, which stages device tensors through the host; RCCL refuses two ranks on one
+device), so this checks what the 8-GPU run relies on: static b % world sharding + ONE sum all-reduce of the flat gradient
+buffer + the identical fused update give every rank the parameters of the single-rank step (train.cpp:604-606,756-766)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ARCH = ("conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu\n"
+        "conv32,ks3,stride2+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu+conv_trans16,ks2,stride2\n"
+        "conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu+conv4,ks1,stride1")
+N = 16
+
+
+def _run(rank, world, port, steps, batch, dtype, out):
+    import unet_studio_amd as U
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"
+    m = U.UNet3d(1, 4, ARCH, device=dev, dtype=dtype, seed=0)
+    src = U.SyntheticVolumes(1, 4, (N, N, N), dev, cache=8)
+    tr = U.Trainer(m, U.TrainingParam(batch_size=batch, epoch=100, learning_rate=0.05), lambda i: src(i % 8), rank, world)
+    stats = []
+    for _ in range(steps):
+        stats.append(tr.step().clone())
+    torch.cuda.synchronize()
+    out[rank] = (m.flat_params.cpu().numpy(), torch.stack(stats).cpu().numpy())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_two_rank_gpu_step_equals_single_rank(dtype):
+    steps, batch = 3, 4
+    mgr = mp.Manager()
+    single, out = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, 0, steps, batch, dtype, single), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), steps, batch, dtype, out), nprocs=2, join=True)
+    p0, s0 = out[0]
+    p1, s1 = out[1]
+    assert np.array_equal(p0, p1), "ranks diverged: the update is not identical on every rank"
+    ref, sref = single[0]
+    # the two-rank sum adds the micro-step gradients in a different order than the single buffer does: fp32 rounding only
+    tol = 1e-5 if dtype == "fp32" else 1e-4
+    assert np.allclose(p0, ref, rtol=tol, atol=tol)
+    assert np.allclose(s0, sref, rtol=1e-4, atol=1e-5)
+    assert np.allclose(s0, s1)
