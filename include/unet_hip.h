@@ -92,6 +92,15 @@ int unet_forward(const unet_plan* plan, const float* const* params, float* const
 int unet_backward(const unet_plan* plan, const float* const* params, const float* const* grad_outs,
                   float* const* grad_params, float* grad_x, void* workspace, void* stream);
 
+/* The same backward issued in parts, so that a host can start the all-reduce of a finished gradient bucket while the rest of
+ * the backward runs (replaces the serial reduce-to-root of add_gradient_from, unet.cpp:224-244; train.cpp:756-757).
+ * unet_plan_backward_buckets: bucket k covers ops [op_lo[k], op_lo[k-1]) (op_lo[-1] = "all", pass a large op_hi) and, once run,
+ * leaves the gradients of the flat parameter elements [elem_lo[k], elem_lo[k-1]) final (elem_lo[-1] = parameter count).
+ * unet_backward_part runs ops [op_lo, op_hi) of the backward; calling it for the buckets in order equals unet_backward. */
+int unet_plan_backward_buckets(const unet_plan* plan, int max_buckets, int* n_buckets, int* op_lo, int64_t* elem_lo);
+int unet_backward_part(const unet_plan* plan, const float* const* params, const float* const* grad_outs, float* const* grad_params,
+                       float* grad_x, void* workspace, int op_hi, int op_lo, void* stream);
+
 /* calc_losses over all deep-supervision levels (train.cpp:501-552,634-706).
  * target: int64 {1,D,H,W} labels (values >= out_c are masked out); cost_mask bit0 ce, bit1 dice, bit2 mse
  * (0 behaves as ce only: train.cpp:696-697); collapse_before as calc_losses.

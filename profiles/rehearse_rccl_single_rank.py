@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-GPU rehearsal of the collective calls bench.py / Trainer make at N > 1 (RCCL group of one rank): process-group init with
-device_id, broadcast of the flat parameters, all-reduce of the flat gradient buffer and of the loss statistics between the
+device_id, broadcast of the flat parameters, asynchronous all-reduces of the gradient buckets under the rest of the backward, of the loss statistics, between the
 backward (whose parameter gradients come from the plan's side stream) and the fused optimizer step, barrier, destroy."""
 import os, sys, time
 import torch
@@ -22,10 +22,12 @@ ref.create_optimizer(0.001)
 stats = torch.zeros(4, device="cuda:0")
 for step in range(5):
     x, t = src(step % 2)
-    l = m.forward_backward(x, t)
+    works = []
+    l = m.forward_backward_bucketed(x, t, lambda lo, hi: works.append(dist.all_reduce(m.flat_grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
     stats.copy_(l)
-    dist.all_reduce(m.flat_grads, op=dist.ReduceOp.SUM)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    for w in works:
+        w.wait()
     m.optimizer.step(grad_scale=1.0, clip_norm=12.0)
     ref.forward_backward(x, t)
     ref.optimizer.step(grad_scale=1.0, clip_norm=12.0)

@@ -328,6 +328,31 @@ def test_default_arch_128_bf16_against_golden(golden_dir):
     assert np.allclose(gl2[big], d["grad_l2"][big], rtol=8e-2)
 
 
+def test_backward_in_buckets_equals_one_backward():
+    """unet_backward_part over unet_plan_backward_buckets = unet_backward, bit for bit; every bucket callback sees final gradients
+    for its element range (what the data-parallel trainer all-reduces under the rest of the backward)"""
+    n = 32
+    m = U.UNet3d(1, 6, U.default_feature(6), device=DEV, dtype="bf16", seed=0)
+    x, t = U.SyntheticVolumes(1, 6, (n, n, n), DEV)(0)
+    m.train()
+    l1 = m.forward_backward(x, t).clone(); g1 = m.flat_grads.clone()
+    m.flat_grads.zero_()
+    seen = []
+
+    def on_bucket(lo, hi):
+        torch.cuda.synchronize()
+        assert torch.equal(m.flat_grads[lo:hi], g1[lo:hi]), "bucket [%d, %d) not final when announced" % (lo, hi)
+        seen.append((lo, hi))
+    l2 = m.forward_backward_bucketed(x, t, on_bucket)
+    assert torch.equal(l1, l2) and torch.equal(m.flat_grads, g1)
+    assert len(seen) == 3 and seen[0][1] == m.flat_grads.numel() and seen[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(seen[:-1], seen[1:]))          # contiguous, from the end of the buffer to its start
+    assert seen[0][0] == 7600464 and seen[1][0] == 879696                  # decoder | encoder levels 5-4 | encoder levels 3-0
+    # an architecture whose parameters are few: one bucket
+    m2 = U.UNet3d(1, 3, "conv4\nconv4\nconv3,ks1", device=DEV, dtype="fp32", seed=0)
+    assert m2.plan_for((8, 8, 8)).backward_buckets(1) == [(0, 0)]
+
+
 @pytest.mark.parametrize("collapse", [0, 2])
 def test_fused_loss_vs_oracle(collapse):
     """calc_losses (train.cpp:501-552): collapse_before, labels >= out_count masked, each cost switch"""

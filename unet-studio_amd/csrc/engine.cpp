@@ -389,7 +389,11 @@ struct Exec {
         }
     }
 
-    void backward(const float* const* params, const float* const* grad_outs, float* const* gparams, float* grad_x) {
+    // Ops [op_lo, op_hi) are run (in reverse); ops >= op_hi are only replayed on the host (dry) to rebuild which gradient buffers
+    // already hold a value: that state depends on the graph and on which grad_outs are given, not on earlier calls, so the
+    // backward can be issued in parts (unet_backward_part) with collectives of finished gradient buckets in between.
+    void backward(const float* const* params, const float* const* grad_outs, float* const* gparams, float* grad_x, int op_hi = 1 << 30,
+                  int op_lo = 0) {
         const Graph& g = p.g;
         std::vector<char> init(g.tensors.size(), 0);
         auto dst_of = [&](int t) {
@@ -412,12 +416,14 @@ struct Exec {
             HIP_OK(hipEventRecord(p.ev_fork, s));
             HIP_OK(hipStreamWaitEvent(sb, p.ev_fork, 0));
         };
-        for (int i = (int)g.ops.size() - 1; i >= 0; --i) {
+        if (op_lo < 0) op_lo = 0;
+        for (int i = (int)g.ops.size() - 1; i >= op_lo; --i) {
             const Op& op = g.ops[i];
+            const bool dry = i >= op_hi;
             if (op.kind == OP_NORM) continue;
             if (op.kind == OP_EXPORT) {
                 if (grad_outs && grad_outs[op.out_level] && g.tensors[op.src[0]].needs_grad) {
-                    launch_export_bwd(p.dtype, grad_outs[op.out_level], dst_of(op.src[0]), g.tensors[op.src[0]].voxels(), s);
+                    if (!dry) launch_export_bwd(p.dtype, grad_outs[op.out_level], dst_of(op.src[0]), g.tensors[op.src[0]].voxels(), s);
                     mark(op);
                 }
                 continue;
@@ -428,16 +434,16 @@ struct Exec {
                 if (p.impl == UNET_IMPL_AUTO && head_supported(geom(op), op.nsrc)) {
                     // fused head backward: dL/dW, dL/db and dL/d(source view) in one pass over (source, dL/dresults[level])
                     DstGrad dgh = dst_of(op.src[0]);
-                    launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
+                    if (!dry) launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
                                     gparams[op.weight], gparams[op.bias], ws + p.head_off, s);
                     if (dgh.ptr) mark(op);
                     continue;
                 }
-                launch_import_grad(p.dtype, grad_outs[op.out_level], gptr(t), g.tensors[t].C, g.tensors[t].voxels(), 0, s);
+                if (!dry) launch_import_grad(p.dtype, grad_outs[op.out_level], gptr(t), g.tensors[t].C, g.tensors[t].voxels(), 0, s);
                 init[t] = 1;
             }
             if (!g.tensors[t].needs_grad || !init[t]) continue;
-            view_backward(t, params, gparams);
+            if (!dry) view_backward(t, params, gparams);
             switch (op.kind) {
                 case OP_CONV:
                 case OP_CONVT: {
@@ -446,25 +452,26 @@ struct Exec {
                     ConvGeom cg = geom(op);
                     const float* wd = (const float*)(ws + p.w_dgrad[i]);
                     bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
-                    fork();
+                    if (!dry) fork();
                     if (op.kind == OP_CONV) {
-                        if (p.wgrad_mfma[i])
+                        if (dry) {
+                        } else if (p.wgrad_mfma[i])
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
                             launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else
                             launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
-                        if (any && p.dgrad_mfma[i]) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
-                        else if (any) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
+                        if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        else if (!dry && (any)) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
                         if (p.wgrad_mfma[i]) {
-                            launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + p.wgrad_off, sb);
-                            launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
+                            if (!dry) launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + p.wgrad_off, sb);
+                            if (!dry) launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
                         } else {
-                            launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+                            if (!dry) launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         }
-                        if (any && p.dgrad_mfma[i]) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
-                        else if (any) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
+                        if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        else if (!dry && (any)) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     }
                     if (any) mark(op);
                     break;
@@ -473,7 +480,7 @@ struct Exec {
                     DstGrad dg[2] = {dst_of(op.src[0]), op.nsrc > 1 ? dst_of(op.src[1]) : DstGrad()};
                     if (dg[0].ptr || (op.nsrc > 1 && dg[1].ptr)) {
                         // the materialized tensor is act(norm(src)): its gradient passes to the view of src unchanged
-                        launch_materialize_bwd(p.dtype, gptr(t), dg, op.nsrc, g.tensors[t].voxels(), s);
+                        if (!dry) launch_materialize_bwd(p.dtype, gptr(t), dg, op.nsrc, g.tensors[t].voxels(), s);
                         mark(op);
                     }
                     break;
@@ -481,17 +488,17 @@ struct Exec {
                 case OP_MAXPOOL: {
                     const Tensor& a = g.tensors[op.src[0]];
                     DstGrad d = dst_of(op.src[0]);
-                    if (d.ptr) { launch_maxpool_bwd(p.dtype, src(op.src[0]), gptr(t), d, a.D, a.H, a.W, s); mark(op); }
+                    if (d.ptr) { if (!dry) launch_maxpool_bwd(p.dtype, src(op.src[0]), gptr(t), d, a.D, a.H, a.W, s); mark(op); }
                     break;
                 }
                 case OP_UPSAMPLE: {
                     const Tensor& a = g.tensors[op.src[0]];
                     DstGrad d = dst_of(op.src[0]);
-                    if (d.ptr) { launch_upsample_bwd(p.dtype, gptr(t), d, a.D, a.H, a.W, s); mark(op); }
+                    if (d.ptr) { if (!dry) launch_upsample_bwd(p.dtype, gptr(t), d, a.D, a.H, a.W, s); mark(op); }
                     break;
                 }
                 case OP_PACK_INPUT:
-                    if (grad_x) launch_unpack_ncdhw(p.dtype, gptr(t), grad_x, g.in_c, g.tensors[t].voxels(), s);
+                    if (!dry && (grad_x)) launch_unpack_ncdhw(p.dtype, gptr(t), grad_x, g.in_c, g.tensors[t].voxels(), s);
                     break;
                 default: break;
             }
@@ -662,6 +669,61 @@ int unet_backward(const unet_plan* p, const float* const* params, const float* c
         Exec ex(*p, workspace, stream);
         ex.backward(params, grad_outs, grad_params, grad_x);
         check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int unet_backward_part(const unet_plan* p, const float* const* params, const float* const* grad_outs, float* const* grad_params,
+                       float* grad_x, void* workspace, int op_hi, int op_lo, void* stream) {
+    try {
+        if (!p || !params || !grad_params || !workspace) throw std::runtime_error("unet_backward_part: null argument");
+        if (op_lo < 0 || op_hi < op_lo) throw std::runtime_error("unet_backward_part: invalid op range");
+        DeviceGuard dg(p->device);
+        Exec ex(*p, workspace, stream);
+        ex.backward(params, grad_outs, grad_params, grad_x, op_hi, op_lo);
+        check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+// Buckets of the backward for overlapping the gradient all-reduce with it: bucket k = ops [op_lo[k], op_lo[k-1]) (op_lo[-1] = number
+// of ops); when it has run, the gradients of the flat parameter elements [elem_lo[k], elem_lo[k-1]) are final.  A cut is made when the
+// parameters finished since the last cut reach total/(max_buckets - 0.5) elements; the last bucket ends at op 0 / element 0.
+int unet_plan_backward_buckets(const unet_plan* p, int max_buckets, int* n_buckets, int* op_lo, int64_t* elem_lo) {
+    try {
+        if (!p || !n_buckets || !op_lo || !elem_lo || max_buckets < 1) throw std::runtime_error("unet_plan_backward_buckets: bad argument");
+        const Graph& g = p->g;
+        const int nops = (int)g.ops.size();
+        // first flat element of the parameters an op's backward finishes (conv/conv_trans: weight, bias and the norm layer recorded
+        // on its output); INT64_MAX for ops without parameters
+        std::vector<int64_t> first(nops, INT64_MAX);
+        bool monotone = true;
+        int64_t prev = -1;
+        for (int i = 0; i < nops; ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
+            int64_t f = p->p_off[op.weight];
+            if (op.bias >= 0 && p->p_off[op.bias] < f) f = p->p_off[op.bias];
+            first[i] = f;
+            if (f <= prev) monotone = false;
+            prev = f;
+            const Tensor& T = g.tensors[op.dst];
+            if (T.norm >= 0) {
+                const Norm& n = g.norms[T.norm];
+                if (p->p_off[n.gamma] < f || p->p_off[n.beta] < f) monotone = false;   // must lie behind the conv's own parameters
+            }
+        }
+        int nb = 0;
+        if (monotone && max_buckets > 1) {
+            const double thr = (double)p->n_param_elems / ((double)max_buckets - 0.5);
+            int64_t hi = p->n_param_elems;
+            for (int i = nops - 1; i > 0 && nb < max_buckets - 1; --i) {
+                if (first[i] == INT64_MAX) continue;
+                if ((double)(hi - first[i]) >= thr) { op_lo[nb] = i; elem_lo[nb] = first[i]; hi = first[i]; ++nb; }
+            }
+        }
+        op_lo[nb] = 0; elem_lo[nb] = 0; ++nb;
+        *n_buckets = nb;
         return 0;
     } catch (const std::exception& e) { return fail(e.what()); }
 }

@@ -50,6 +50,8 @@ _sig("unet_plan_flops", _i, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("unet_plan_describe", _sz, _vp, C.c_char_p, _sz)
 _sig("unet_forward", _i, _vp, _pp, _pp, _vp, _pp, _vp, _i, _vp)
 _sig("unet_backward", _i, _vp, _pp, _pp, _pp, _vp, _vp, _vp)
+_sig("unet_backward_part", _i, _vp, _pp, _pp, _pp, _vp, _vp, _i, _i, _vp)
+_sig("unet_plan_backward_buckets", _i, _vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int64))
 _sig("unet_loss_scratch_bytes", _i, _vp, C.POINTER(_sz))
 _sig("unet_loss", _i, _vp, _pp, _vp, _i, _i, _pp, _vp, _vp, _vp)
 _sig("unet_sgd_step", _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _f, _vp, _vp, _vp)
@@ -71,7 +73,7 @@ EXPORTS = [
     "unet_last_error", "unet_init", "unet_device_info", "unet_plan_create", "unet_plan_destroy", "unet_plan_param_count",
     "unet_plan_param_shape", "unet_plan_param_name", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
     "unet_plan_buffer_shape", "unet_plan_output_count", "unet_plan_output_shape", "unet_plan_workspace_bytes",
-    "unet_plan_flops", "unet_plan_describe", "unet_forward", "unet_backward", "unet_loss_scratch_bytes", "unet_loss",
+    "unet_plan_flops", "unet_plan_describe", "unet_forward", "unet_backward", "unet_backward_part", "unet_plan_backward_buckets", "unet_loss_scratch_bytes", "unet_loss",
     "unet_sgd_step", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_pack", "unet_op_conv3d_fwd_packed", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
     "unet_op_convt_fwd", "unet_op_convt_bwd_data", "unet_op_convt_bwd_weight", "unet_op_pack_ndhwc", "unet_op_unpack_ncdhw",
 ]
@@ -136,6 +138,14 @@ class Plan:
         f, g = C.c_double(), C.c_double()
         check(lib.unet_plan_flops(self.handle, C.byref(f), C.byref(g)))
         self.flops_fwd, self.flops_bwd = f.value, g.value
+
+    def backward_buckets(self, max_buckets=3):
+        """[(op_lo, elem_lo)]: running the backward for ops [op_lo[k], op_lo[k-1]) finishes the gradients of the flat parameter
+        elements [elem_lo[k], elem_lo[k-1]) -- the unit an overlapped all-reduce works on"""
+        n = C.c_int()
+        ops, el = (C.c_int * max_buckets)(), (C.c_int64 * max_buckets)()
+        check(lib.unet_plan_backward_buckets(self.handle, max_buckets, C.byref(n), ops, el))
+        return [(ops[k], el[k]) for k in range(n.value)]
 
     def describe(self):
         n = lib.unet_plan_describe(self.handle, None, 0)

@@ -8,6 +8,7 @@ train.cpp:573-579) becomes ONE sum all-reduce of the flat fp32 gradient buffer o
 which every rank applies the identical update -- no broadcast needed.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -48,6 +49,8 @@ class Trainer:
     def __init__(self, model, param, source, rank=0, world_size=1, group=None):
         self.model, self.param, self.source = model, param, source
         self.rank, self.world_size, self.group = rank, world_size, group
+        # world_size > 1: start the all-reduce of every finished gradient bucket under the rest of the backward
+        self.overlap = os.environ.get("UNET_NO_OVERLAP") is None
         self.cur_epoch = 0
         model.train()
         if model.optimizer is None:
@@ -66,15 +69,30 @@ class Trainer:
             g["lr"] = self.lr_at(self.cur_epoch)
         self._stats.zero_()
         count = 0
-        for b in range(self.rank, p.batch_size, self.world_size):
+        mine = list(range(self.rank, p.batch_size, self.world_size))
+        works = []
+        overlap = self.world_size > 1 and self.overlap and hasattr(m, "forward_backward_bucketed")
+
+        def reduce_bucket(lo, hi):   # the bucket's gradients are final: sum them over the replicas under the rest of the backward
+            if hi > lo:
+                works.append(dist.all_reduce(m.flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        for k, b in enumerate(mine):
             x, t = self.source(cur_data_index + b)
-            losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse)
+            if overlap and k == len(mine) - 1:
+                # gradients accumulate over this rank's micro-steps: only the last backward can hand finished buckets to RCCL
+                losses = m.forward_backward_bucketed(x, t, reduce_bucket, p.cost_ce, p.cost_dice, p.cost_mse)
+            else:
+                losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse)
             self._stats += losses
             count += 1
         if self.world_size > 1:
-            # gradient sum over replicas (unet.cpp:224-244 -> one RCCL all-reduce of the flat buffer)
-            dist.all_reduce(m.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+            # gradient sum over replicas (unet.cpp:224-244 -> RCCL all-reduce of the flat buffer, in buckets when overlapped)
+            if not works:
+                dist.all_reduce(m.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self._stats, op=dist.ReduceOp.SUM, group=self.group)  # loss-stat gather, train.cpp:732-741
+            for w in works:
+                w.wait()
         m.optimizer.step(grad_scale=1.0 / p.batch_size, clip_norm=12.0)  # train.cpp:759-766
         self.cur_epoch += 1
         return self._stats

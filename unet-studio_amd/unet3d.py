@@ -264,6 +264,29 @@ class UNet3d:
         E.check(E.lib.unet_backward(plan.handle, pp, go, gp, grad_x.data_ptr() if grad_x is not None else None,
                                     ws.data_ptr(), _stream_ptr(self._device)))
 
+    def _run_backward_part(self, plan, ws, grad_outs, op_hi, op_lo):
+        pp = E.ptr_array([p.data_ptr() for p in self._params])
+        gp = E.ptr_array([g.data_ptr() for g in self._grads])
+        go = E.ptr_array([g.data_ptr() if g is not None else None for g in grad_outs])
+        E.check(E.lib.unet_backward_part(plan.handle, pp, go, gp, None, ws.data_ptr(), op_hi, op_lo, _stream_ptr(self._device)))
+
+    def forward_backward_bucketed(self, x, target, on_bucket, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0,
+                                  max_buckets=3):
+        """forward_backward with the backward issued in buckets: on_bucket(elem_lo, elem_hi) is called after each part, when the
+        gradients flat_grads[elem_lo:elem_hi] are final on the current stream (the data-parallel trainer starts their all-reduce
+        there, so that it runs under the rest of the backward)."""
+        x = self._check_input(x)
+        plan = self.plan_for(x.shape[2:])
+        ws = self._workspace(plan)
+        outs = self._run_forward(plan, ws, x, mode=1)
+        losses, gouts = self.loss(outs, target, cost_ce, cost_dice, cost_mse, collapse_before, plan=plan)
+        op_hi, elem_hi = 1 << 30, int(self.flat_grads.numel())
+        for op_lo, elem_lo in plan.backward_buckets(max_buckets):
+            self._run_backward_part(plan, ws, gouts, op_hi, op_lo)
+            on_bucket(int(elem_lo), elem_hi)
+            op_hi, elem_hi = op_lo, int(elem_lo)
+        return losses
+
     def _check_input(self, x):
         if x.dim() != 5 or x.size(0) != 1 or x.size(1) != self.in_count:
             raise E.UNetError("forward expects a {1,%d,D,H,W} tensor, got %s" % (self.in_count, tuple(x.shape)))
