@@ -270,15 +270,30 @@ struct Exec {
         const Graph& g = p.g;
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
         // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
-        bool packed = false;
+        bool packed = false, pack_pending = false;
         if (p.jobs_dev) {
             bool flat = true;
             for (size_t i = 0; i < g.params.size() && flat; ++i) flat = params[i] == params[0] + p.p_off[i];
             if (flat) {
-                launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, s);
+                // training forward: the pack runs on the plan's side stream beside the input pack, the first conv (which reads the
+                // fp32 filter) and its norm; the first kernel that needs packed filters waits for it.  (Eval forwards stay on the
+                // caller's stream: they are re-entrant per workspace, the side stream and its events are per plan.)
+                static const bool no_side = getenv("UNET_NO_SIDE_STREAM") != nullptr;
+                if (mode == 1 && p.side && !no_side) {
+                    HIP_OK(hipEventRecord(p.ev_fork, s));
+                    HIP_OK(hipStreamWaitEvent(p.side, p.ev_fork, 0));
+                    launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, p.side);
+                    HIP_OK(hipEventRecord(p.ev_join, p.side));
+                    pack_pending = true;
+                } else {
+                    launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, s);
+                }
                 packed = true;
             }
         }
+        auto need_packs = [&]() {
+            if (pack_pending) { HIP_OK(hipStreamWaitEvent(s, p.ev_join, 0)); pack_pending = false; }
+        };
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             switch (op.kind) {
@@ -292,6 +307,7 @@ struct Exec {
                     ConvGeom cg = geom(op);
                     float* wf = (float*)(ws + p.w_fwd[i]);
                     float* wd = (float*)(ws + p.w_dgrad[i]);
+                    if (p.use_mfma[i]) need_packs();
                     if (op.kind == OP_CONV && p.use_mfma[i]) {
                         if (!packed)
                             launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i],
@@ -373,6 +389,7 @@ struct Exec {
                 if (T.norm < 0 && T.act != ACT_NONE) apply_view(op.dst);
             }
         }
+        need_packs();   // nothing consumed the packs (no MFMA op): still order the caller's stream after the side stream
     }
 
     // g[t] holds dL/d(view of t); turn it into dL/d(raw t) (and accumulate the norm's affine gradients)
