@@ -12,12 +12,15 @@
 //   * A operand  = filter tile, pre-packed in fragment order (one 16-B load per lane, L2-resident).
 //   * B operand  = input patches, ds_read_b128 from an LDS halo tile [HZ][HY][HX][CK channels] staged once per
 //                  CK-channel chunk and re-used by all taps.
-//   * the producer's norm + activation (scale/shift per channel, then relu/leaky/elu) is applied while staging,
-//     zero padding after it (padding pads the ACTIVATED tensor); a channel concat {skip, x} (unet.cpp:181) is just
-//     a second source pointer.
-//   * epilogue: + bias, round to bf16, 8-B stores (4 consecutive channels per lane); optional per-block
-//     {sum, sum of squares} per channel for the following norm; optional accumulate / two destinations (dgrad
+//   * sources are PLAIN bf16 tensors: a tensor with a recorded norm + activation is read through its activated copy (the
+//     engine writes it once after the statistics; transforming while staging cost +85 % of the kernel).  Zero padding pads
+//     the activated tensor; a channel concat {skip, x} (unet.cpp:181) is just a second source pointer.
+//   * epilogue: + bias, round to bf16, 8-B stores (4 consecutive channels per lane); optional {sum, sum of squares} per
+//     channel for the following norm, one partial row per persistent block; optional accumulate / two destinations (dgrad
 //     of a concat); SC = depth-to-space scatter: row block `tap` goes to output voxel 2*v + tap.
+//   Kernels in this file: k_mfma_conv_p (persistent halo-tile form, every kind), k_mfma_conv_z (sliding window along z for the
+//   single-chunk 32-channel stride-1 layers), k_mfma_conv_small (16^3 and smaller volumes), k_conv_first_mfma (Cin = 1),
+//   k_mfma_pack / k_mfma_pack_batched (fp32 torch layout -> bf16 fragments).
 #include <type_traits>
 #include "mfma_util.h"
 
@@ -165,10 +168,10 @@ static void run_pack(const float* w, void* out, int Ci, int Co, int CK, int T, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent, software-pipelined form of the kernel above (same maths, same arguments).  A block walks
+// Persistent, software-pipelined kernel.  A block walks
 // tiles bid, bid + gridDim.x, ...; one pipeline stage = one (tile, channel chunk).  The global loads of
 // stage s+1 are issued into registers BEFORE the MFMAs of stage s and written to LDS after them, so HBM/L2
-// latency hides under the matrix work even at 2 blocks per CU (measured: the one-shot kernel spent ~6 % of
+// latency hides under the matrix work even at 2 blocks per CU (measured: the first, one-tile-per-block version spent ~6 % of
 // a block's lifetime in MFMAs, the rest waiting for the halo tile).
 // ------------------------------------------------------------------------------------------------
 // ONE: Cin == CK is known at compile time (the two heaviest layers, 32->16 and 16->16 at 128^3): the filter fragments are
