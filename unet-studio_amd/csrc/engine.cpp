@@ -180,6 +180,10 @@ struct unet_plan {
                 b = wgrad_small_scratch_bytes(cg);
                 if (b > wmax) wmax = b;
             }
+            if (op.kind == OP_CONV && cg.Cin == 1 && (cg.Cout == 16 || cg.Cout == 32)) {
+                b = conv_first_wgrad_mfma_scratch_bytes(cg);
+                if (b > wmax) wmax = b;
+            }
             if (op.kind == OP_CONV && head_supported(cg, op.nsrc)) {
                 b = head_bwd_scratch_bytes(cg);
                 if (b > hmax) hmax = b;
@@ -472,7 +476,9 @@ struct Exec {
                     if (!dry) fork();
                     if (op.kind == OP_CONV) {
                         if (dry) {
-                        } else if (p.wgrad_mfma[i])
+                        } else if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc))
+                            launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+                        else if (p.wgrad_mfma[i])
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
                             launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
@@ -958,6 +964,8 @@ int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy
         SrcDesc sd; sd.ptr = x; sd.C = cin;
         if (impl == UNET_IMPL_AUTO && mfma_wgrad_supported(dtype, g, &sd, 1))
             launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
+        else if (impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(dtype, g, &sd, 1))
+            launch_conv_first_wgrad_mfma(g, &sd, dy, dw, db, scratch, (hipStream_t)stream);
         else if (impl == UNET_IMPL_AUTO && wgrad_small_supported(g, 1))
             launch_conv_wgrad_small(dtype, g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
         else

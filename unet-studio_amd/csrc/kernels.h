@@ -154,6 +154,10 @@ void launch_head_fwd(int dtype, const ConvGeom& g, const SrcDesc& src, const flo
                      hipStream_t s);
 void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* dy_ncdhw, const void* dy_cl, const float* w,
                      DstGrad dst, float* dw, float* db, void* scratch, hipStream_t s);
+// wgrad (+ bias grad) of the first conv (Cin = 1, 3x3x3 stride 1, Cout 16 or 32, plain bf16 input) on the matrix cores
+bool conv_first_wgrad_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g);
+void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s);
 bool wgrad_small_supported(const ConvGeom& g, int nsrc);
 size_t wgrad_small_scratch_bytes(const ConvGeom& g);
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,

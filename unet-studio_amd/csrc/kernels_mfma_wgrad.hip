@@ -361,6 +361,141 @@ static void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, 
     else k_mfma_wgrad_reduce<32><<<cdiv64(ntot, 32), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad of the network's first conv (Cin = 1, 3x3x3 stride 1, Cout = 16 * NT) on the matrix cores:
+//     D[tap][co] = sum_voxels x[voxel + tap] * dy[voxel][co]        M = 27 taps (+ row 27 = ones: the bias gradient), K = voxels
+// A tile is 2 x 8 rows of 32 voxels; the input halo sits in LDS three times, shifted by 0 / 1 / 2 elements, so that the 8
+// consecutive voxels a lane needs for tap kx are one aligned 16-B read; dy is gathered with 2-byte reads (voxel stride padded
+// against bank conflicts).  4 waves split the rows; partial D's are summed through LDS and written as one slab row per block.
+// (The VALU kernel it replaces, k_wgrad_first, was the exposed tail of the backward: it needs dL/d(raw) of the first norm layer.)
+// ------------------------------------------------------------------------------------------------
+struct FirstWgradArgs {
+    ConvGeom g;
+    const void* x;      // bf16 [D][H][W]
+    const void* dy;     // bf16 [D][H][W][Cout]
+    float* slab;        // [gridDim.x][27 * Cout]
+    float* bslab;       // [gridDim.x][Cout]
+    int tiles_x, tiles_y, tiles_z;
+};
+template <int NT>
+__global__ void __launch_bounds__(256, 2) k_wgrad_first_mfma(FirstWgradArgs a) {
+    constexpr int TZ = 2, TY = 8, TX = 32, HZ = TZ + 2, HY = TY + 2, NROW = TZ * TY, CO = 16 * NT;
+    constexpr int XCOPY = HZ * HY * TX;                 // elements of one shifted copy of the halo
+    constexpr int VSB = CO * 2 + 4;                     // bytes per dy voxel in LDS (padded: k-groups 8 voxels apart hit different banks)
+    constexpr int DY_OFF = 3 * XCOPY * 2;
+    __shared__ __attribute__((aligned(16))) char sm[DY_OFF + NROW * TX * VSB + 16];
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
+    const unsigned short* x = (const unsigned short*)a.x;
+    const char* dyb = (const char*)a.dy;
+    // A operand: lane (row = tap, k group gq); taps 27..31 of the second row tile read tap 26's patch (finite; rows never stored)
+    int abase[2];
+    bool ones_row = false;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        int tap = rt * 16 + j;
+        if (tap == 27) ones_row = true;
+        if (tap > 26) tap = 26;
+        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        abase[rt] = (kx * XCOPY + (kz * HY + ky) * TX + gq * 8) * 2;
+    }
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int x0 = (t % a.tiles_x) * TX, y0 = ((t / a.tiles_x) % a.tiles_y) * TY, z0 = (t / (a.tiles_x * a.tiles_y)) * TZ;
+        __syncthreads();
+        // input halo, three shifted copies: copy s holds x[.., x0 - 1 + i + s] at element i
+        for (int e = tid; e < HZ * HY * (TX + 2); e += 256) {
+            const int hx = e % (TX + 2), r = e / (TX + 2), hy = r % HY, hz = r / HY;
+            const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            unsigned short v = 0;
+            if ((unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W) v = x[((size_t)gz * g.H + gy) * g.W + gx];
+#pragma unroll
+            for (int sft = 0; sft < 3; ++sft) {
+                const int i = hx - sft;
+                if (i >= 0 && i < TX) *(unsigned short*)(sm + (sft * XCOPY + (hz * HY + hy) * TX + i) * 2) = v;
+            }
+        }
+        // dy tile [row][voxel][co] (16-B global reads, 4-B LDS stores)
+        for (int u = tid; u < NROW * TX * (CO / 8); u += 256) {
+            const int c8 = u % (CO / 8), vx = (u / (CO / 8)) % TX, row = u / ((CO / 8) * TX);
+            const int gz = z0 + row / TY, gy = y0 + row % TY, gx = x0 + vx;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gz < g.D && gy < g.H && gx < g.W) v = *(const uint4*)(dyb + ((((size_t)gz * g.H + gy) * g.W + gx) * CO + c8 * 8) * 2);
+            unsigned* d = (unsigned*)(sm + DY_OFF + (row * TX + vx) * VSB + c8 * 16);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int row = wave; row < NROW; row += 4) {      // one K-step = the 32 voxels of output row `row`
+            const int rz = row / TY, ry = row % TY;
+            const int roff = (rz * HY + ry) * TX * 2;
+            bf16x8 af[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) af[rt] = *(const bf16x8*)(sm + abase[rt] + roff);
+            if (ones_row) af[1] = ones;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                unsigned d[4];
+                const char* pb = sm + DY_OFF + (row * TX + gq * 8) * VSB + (n * 16 + j) * 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned lo = *(const unsigned short*)(pb + (2 * e) * VSB), hi = *(const unsigned short*)(pb + (2 * e + 1) * VSB);
+                    d[e] = lo | (hi << 16);
+                }
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(d[0], d[1], d[2], d[3]));
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt], bf, acc[rt][n], 0, 0, 0);
+            }
+        }
+    }
+    // sum the four waves' partial D through LDS, write the slab row: dw[co][0][tap] then db[co]
+    __syncthreads();
+    float* red = (float*)sm;                                // [4 waves][2][NT][64 lanes][4]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) *(f32x4*)(red + (((wave * 2 + rt) * NT + n) * 64 + lane) * 4) = acc[rt][n];
+    __syncthreads();
+    const int O = 27 * g.Cout;
+    float* sl = a.slab + (size_t)blockIdx.x * O;
+    for (int e = tid; e < 2 * NT * 256; e += 256) {        // e = ((rt*NT + n)*64 + lane')*4 + reg
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[w * 2 * NT * 256 + e];
+        const int reg = e & 3, l2 = (e >> 2) & 63, rn = e >> 8, n = rn % NT, rt = rn / NT;
+        const int tap = rt * 16 + 4 * (l2 >> 4) + reg, co = n * 16 + (l2 & 15);
+        if (tap < 27) sl[co * 27 + tap] = v;
+        else if (tap == 27) a.bslab[(size_t)blockIdx.x * g.Cout + co] = v;
+    }
+}
+bool conv_first_wgrad_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    return dtype == 1 && nsrc == 1 && g.Cin == 1 && g.ks == 3 && g.stride == 1 && (g.Cout == 16 || g.Cout == 32) && !src[0].scale &&
+           src[0].act == 0;
+}
+static int first_wgrad_blocks(const ConvGeom& g) {
+    int tiles = ((g.W + 31) / 32) * ((g.H + 7) / 8) * ((g.D + 1) / 2);
+    return tiles < 512 ? tiles : 512;
+}
+size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g) { return (size_t)first_wgrad_blocks(g) * (27 * g.Cout + g.Cout) * 4 + 256; }
+// dw += , db += (db may be null); scratch: conv_first_wgrad_mfma_scratch_bytes
+void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s) {
+    FirstWgradArgs a;
+    a.g = g; a.x = src[0].ptr; a.dy = dy; a.slab = (float*)scratch;
+    a.tiles_x = (g.W + 31) / 32; a.tiles_y = (g.H + 7) / 8; a.tiles_z = (g.D + 1) / 2;
+    const int nb = first_wgrad_blocks(g);
+    const int64_t O = 27 * g.Cout;
+    a.bslab = a.slab + (size_t)nb * O;
+    if (g.Cout == 16) k_wgrad_first_mfma<1><<<nb, 256, 0, s>>>(a);
+    else k_wgrad_first_mfma<2><<<nb, 256, 0, s>>>(a);
+    wgrad_reduce(a.slab, db ? a.bslab : nullptr, nb, O, g.Cout, dw, db, s);
+}
+
 static bool chan16(const ConvGeom& g, const SrcDesc* src, int nsrc) {
     if (g.Cin % 16 || g.Cout % 16) return false;
     for (int s = 0; s < nsrc; ++s)
