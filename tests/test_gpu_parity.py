@@ -328,6 +328,46 @@ def test_default_arch_128_bf16_against_golden(golden_dir):
     assert np.allclose(gl2[big], d["grad_l2"][big], rtol=8e-2)
 
 
+ARCH_NONCUBIC = ("conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu\n"
+                 "conv32,ks3,stride2+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu\n"
+                 "conv64,ks3,stride2+norm,leaky_relu+conv64,ks3,stride1+norm,leaky_relu+conv_trans32,ks2,stride2\n"
+                 "conv32,ks3,stride1+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu+conv5,ks1,stride1+conv_trans16,ks2,stride2\n"
+                 "conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu+conv5,ks1,stride1")
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("size", [(24, 40, 56), (20, 36, 12), (8, 16, 132)])
+def test_noncubic_network_against_live_aten(size, dt):
+    """volumes that are not cubes and not multiples of any tile (ragged sliding-window columns, partial planes, W < 16, long rows):
+    forward, loss and backward against the ATen CPU executor run live IN FLOAT64 (oracle/aten_ref.py).  fp64 because the deepest
+    level normalises over as few as 5 x 9 x 3 voxels: there ATen's own fp32 gradients are 3e-3 away from its fp64 ones."""
+    torch.manual_seed(3)
+    ref = A.UNet3dRef(2, 5, ARCH_NONCUBIC)
+    ref.train()
+    x, t = A.synthetic_sample(2, 5, size, 11)
+    m = U.UNet3d(2, 5, ARCH_NONCUBIC, device=DEV, dtype=dt)
+    m.load_parameters([p.detach().numpy() for p in ref.parameters()])
+    ref = ref.double()
+    outs_ref = ref(x.double())
+    loss_ref, _ = A.deep_supervision_loss(outs_ref, t, 5)
+    loss_ref.backward()
+    xd, td = x.to(DEV), t.to(DEV)
+    plan = m.plan_for(xd.shape[2:]); ws = m._workspace(plan)
+    outs = m._run_forward(plan, ws, xd, 1)
+    for k, (o, r) in enumerate(zip(outs, outs_ref)):
+        e = rel(o[0].cpu().numpy().astype(np.float64), r[0].detach().numpy())
+        assert e < (1e-4 if dt == "fp32" else 8e-2), "logits level %d: %g" % (k, e)
+    losses, gouts = m.loss(outs, td)
+    assert abs(float(losses[0]) - float(loss_ref)) < (1e-4 if dt == "fp32" else 2e-2) * float(loss_ref)
+    m._run_backward(plan, ws, gouts)
+    gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).numpy()
+    g = m.flat_grads.cpu().numpy().astype(np.float64)
+    e = np.abs(g - gref).max() / np.abs(gref).max()
+    # fp32 engine: its direct wgrad kernels accumulate a thread's voxels sequentially in fp32 and dL/d(raw) of a norm layer sums to
+    # zero, so the weight gradients carry ~5e-4 of the largest gradient (ATen's blocked sums: 1e-6); 5e-3 on the tiny deep levels
+    assert e < (5e-3 if dt == "fp32" else 1.5e-1), "gradients: %g" % e
+
+
 def test_backward_in_buckets_equals_one_backward():
     """unet_backward_part over unet_plan_backward_buckets = unet_backward, bit for bit; every bucket callback sees final gradients
     for its element range (what the data-parallel trainer all-reduces under the rest of the backward)"""
