@@ -363,8 +363,9 @@ def test_noncubic_network_against_live_aten(size, dt):
     gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).numpy()
     g = m.flat_grads.cpu().numpy().astype(np.float64)
     e = np.abs(g - gref).max() / np.abs(gref).max()
-    # fp32 engine: its direct wgrad kernels accumulate a thread's voxels sequentially in fp32 and dL/d(raw) of a norm layer sums to
-    # zero, so the weight gradients carry ~5e-4 of the largest gradient (ATen's blocked sums: 1e-6); 5e-3 on the tiny deep levels
+    # fp32 engine: measured 5.5e-4 of the largest gradient on the first size (ATen fp32: 1e-6) -- its norm statistics are
+    # E[x^2] - mean^2 from fp32 block partials and the weight gradient of a conv behind a norm is a sum that cancels to ~1e-3 of its
+    # terms; on the two sizes with tiny deep levels even ATen's fp32 gradients are 3e-3 from its fp64 ones
     assert e < (5e-3 if dt == "fp32" else 1.5e-1), "gradients: %g" % e
 
 
