@@ -335,17 +335,27 @@ ARCH_NONCUBIC = ("conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,lea
                  "conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu+conv5,ks1,stride1")
 
 
+ARCH_MIX_NC = ("conv8,ks3,stride1+norm,elu+conv8,ks3,stride1+norm,leaky_relu\n"
+               "conv16,ks3,stride2+norm,elu+conv16,ks3,stride1+norm,leaky_relu\n"
+               "max_pool+conv16,ks3,stride1+norm,relu+upsample\n"
+               "conv16,ks3,stride1+norm,leaky_relu+conv5,ks1,stride1+conv_trans8,ks2,stride2\n"
+               "conv8,ks3,stride1+norm,leaky_relu+conv5,ks1,stride1")
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("size", [(24, 40, 56), (20, 36, 12), (8, 16, 132)])
+@pytest.mark.parametrize("size", [(24, 40, 56), (20, 36, 12), (8, 16, 132), (12, 20, 28, "mix")])
 def test_noncubic_network_against_live_aten(size, dt):
     """volumes that are not cubes and not multiples of any tile (ragged sliding-window columns, partial planes, W < 16, long rows):
     forward, loss and backward against the ATen CPU executor run live IN FLOAT64 (oracle/aten_ref.py).  fp64 because the deepest
     level normalises over as few as 5 x 9 x 3 voxels: there ATen's own fp32 gradients are 3e-3 away from its fp64 ones."""
+    arch = ARCH_NONCUBIC
+    if len(size) == 4:   # every other layer kind (elu / relu, max_pool, upsample, 8-channel convs on the direct kernels)
+        arch, size = ARCH_MIX_NC, size[:3]
     torch.manual_seed(3)
-    ref = A.UNet3dRef(2, 5, ARCH_NONCUBIC)
+    ref = A.UNet3dRef(2, 5, arch)
     ref.train()
     x, t = A.synthetic_sample(2, 5, size, 11)
-    m = U.UNet3d(2, 5, ARCH_NONCUBIC, device=DEV, dtype=dt)
+    m = U.UNet3d(2, 5, arch, device=DEV, dtype=dt)
     m.load_parameters([p.detach().numpy() for p in ref.parameters()])
     ref = ref.double()
     outs_ref = ref(x.double())
