@@ -16,14 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "unet_hip.h")).read()
-    declared = set(re.findall(r"\b(unet_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"unet_plan"}
-    assert declared, "no declarations parsed"
     lib = ctypes.CDLL(U.engine.LIB_PATH)
-    for name in sorted(declared):
-        assert hasattr(lib, name), "libunet_hip.so does not export " + name
-    assert declared == set(U.engine.EXPORTS)
+    for header, exports in (("unet_hip.h", U.engine.EXPORTS), ("unet_augment.h", U.augment.EXPORTS)):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        declared = set(re.findall(r"\b(unet_[a-z0-9_]+)\s*\(", hdr))
+        declared -= {"unet_plan"}
+        assert declared, "no declarations parsed"
+        for name in sorted(declared):
+            assert hasattr(lib, name), "libunet_hip.so does not export " + name
+        assert declared == set(exports)
 
 
 def test_plan_matches_reference_parameter_order_default_arch():

@@ -7,6 +7,8 @@ from . import engine  # noqa: F401  (raises ImportError when libunet_hip.so is a
 from .engine import DTYPE_BF16, DTYPE_F32, IMPL_AUTO, IMPL_DIRECT, Plan, UNetError  # noqa: F401
 from .unet3d import SGD, UNet3d  # noqa: F401
 from .train import SyntheticVolumes, Trainer, TrainingParam  # noqa: F401
+from . import augment  # noqa: F401
+from .augment import AugmentedVolumes, visual_perception_augmentation  # noqa: F401
 
 
 def default_feature(out_count):

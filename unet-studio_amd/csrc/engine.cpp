@@ -1027,4 +1027,33 @@ int unet_op_unpack_ncdhw(int dtype, const void* x, float* y, int C, int64_t S, v
     OP_TRY({ launch_unpack_ncdhw(dtype, x, y, C, S, (hipStream_t)stream); })
 }
 
+
+// ---- on-GPU sample augmentation (include/unet_augment.h) ----
+static const char* augment_recipe_error(const UnetAugmentRecipe* r) {
+    if (!r) return "unet_augment: null recipe";
+    for (int d = 0; d < 3; ++d)
+        if (r->dims[d] < 1) return "unet_augment: dims must be positive";
+    if (r->channels < 1 || r->channels > UNET_AUG_MAX_CHANNELS) return "unet_augment: channels out of range (1..UNET_AUG_MAX_CHANNELS)";
+    if (r->n_foci < 0 || r->n_foci > UNET_AUG_MAX_FOCI) return "unet_augment: n_foci out of range (0..UNET_AUG_MAX_FOCI)";
+    if (r->trunc_top < 0 || r->trunc_bottom < 0) return "unet_augment: negative truncation";
+    if (r->downsample)
+        for (int d = 0; d < 3; ++d)
+            if (r->low_dims[d] < 1 || r->low_dims[d] > r->dims[d]) return "unet_augment: low_dims must be in 1..dims";
+    for (int k = 0; k < r->n_foci; ++k)
+        if (!(r->foci_radius[k] > 0.f)) return "unet_augment: distortion radius must be positive";
+    return nullptr;
+}
+int unet_augment_scratch_bytes(const UnetAugmentRecipe* recipe, size_t* bytes) {
+    if (const char* e = augment_recipe_error(recipe)) return fail(e);
+    if (!bytes) return fail("unet_augment_scratch_bytes: null output");
+    *bytes = augment_scratch_bytes(*recipe);
+    return 0;
+}
+int unet_augment_run(const UnetAugmentRecipe* recipe, float* image, float* label, void* scratch, size_t scratch_bytes, void* stream) {
+    if (const char* e = augment_recipe_error(recipe)) return fail(e);
+    if (!image || !label || !scratch) return fail("unet_augment_run: null device pointer");
+    if (scratch_bytes < augment_scratch_bytes(*recipe)) return fail("unet_augment_run: scratch too small (see unet_augment_scratch_bytes)");
+    OP_TRY({ launch_augment(*recipe, image, label, scratch, (hipStream_t)stream); })
+}
+
 }  // extern "C"

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#include "../../include/unet_augment.h"
+
 namespace unet {
 
 // A tensor as a consumer sees it: act(x * scale[c] + shift[c]) (scale == nullptr: identity affine).
@@ -181,5 +183,9 @@ size_t mfma_convt_dgrad_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_convt_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
 void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s);
 void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
+
+// kernels_augment.hip: on-GPU sample augmentation (include/unet_augment.h)
+size_t augment_scratch_bytes(const UnetAugmentRecipe& r);
+void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void* scratch, hipStream_t st);
 
 }  // namespace unet
