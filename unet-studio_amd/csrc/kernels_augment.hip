@@ -33,7 +33,35 @@ constexpr int AUG_T = 256;
 struct AugGeom {
     int W, H, D, C;
     int64_t N;
+    int gx, gy, gz;   // tile grid of the gather passes
 };
+
+// Thread -> voxel maps.  The gather passes (view, stamps) read 8 corners around a ROTATED position: with a block on a
+// 16 x 4 x 4 brick its 256 footprints overlap in a compact source region that stays in the CU's L1, where a 256-long row would
+// touch hundreds of cache lines with no reuse between corners (the blend pass at 2 x 256^3: 12.8 ms by rows, 6.6 ms by bricks).  Bricks are numbered so
+// that each XCD (blocks are dealt round-robin to the 8 XCDs) works through one contiguous z-range of the volume and its
+// private L2 keeps that range's halo.
+constexpr int TX = 16, TY = 4, TZ = 4;
+static_assert(TX * TY * TZ == AUG_T, "brick = block");
+
+__device__ __forceinline__ bool brick_voxel(const AugGeom& g, int& x, int& y, int& z) {
+    const unsigned nb = gridDim.x, per = (nb + 7) / 8;
+    const unsigned b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);   // uniform
+    if (b >= nb) { x = y = z = 0; return false; }                     // only when nb is not a multiple of 8: ids >= nb idle
+    const unsigned bx = b % g.gx, r = b / g.gx, by = r % g.gy, bz = r / g.gy;
+    x = bx * TX + (threadIdx.x & (TX - 1));
+    y = by * TY + ((threadIdx.x / TX) & (TY - 1));
+    z = bz * TZ + threadIdx.x / (TX * TY);
+    return x < g.W && y < g.H && z < g.D;
+}
+
+// element-wise passes that need coordinates: a block = 64 (x) x 4 (y) at one z, launched on a 3-D grid
+__device__ __forceinline__ bool row_voxel(int W, int H, int& x, int& y, int& z) {
+    x = blockIdx.x * 64 + (threadIdx.x & 63);
+    y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    z = blockIdx.z;
+    return x < W && y < H;
+}
 
 struct AugPhoto {   // host-derived constants of the element-wise stage, as the reference's host wrappers derive them
     int crop; float crop_pos[3], crop_radius, crop_value;
@@ -78,7 +106,9 @@ __global__ void k_aug_upload(AugTables t, AugTables* dst) {
 enum { CELL_VIEW = 0, CELL_BLEND = UNET_AUG_MAX_CHANNELS, CELL_STAMP = 2 * UNET_AUG_MAX_CHANNELS,
        CELL_PERLIN = CELL_STAMP + UNET_AUG_MAX_CHANNELS * UNET_AUG_STAMPS, CELL_COUNT = CELL_PERLIN + 1 };
 
-__device__ __forceinline__ void block_max_to(unsigned* cell, float v) {
+// Block maximum -> row[blockIdx.x]; k_aug_cells then folds a row into its cell.  (A first version sent one atomicMax per
+// block straight to the cell: 131 k device-scope atomics on one address made the blend pass 6.6 ms instead of 0.8)
+__device__ __forceinline__ void block_max_to(float* __restrict__ row, float v) {
     __shared__ float red[AUG_T / 64];
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     __syncthreads();   // `red` may still be read by a previous call
@@ -87,7 +117,30 @@ __device__ __forceinline__ void block_max_to(unsigned* cell, float v) {
     if (threadIdx.x == 0) {
         float m = red[0];
         for (int i = 1; i < AUG_T / 64; ++i) m = fmaxf(m, red[i]);
-        if (m > 0.f) atomicMax(cell, __float_as_uint(m));
+        row[blockIdx.x] = m;
+    }
+}
+
+// cells[cell_of(row)] = max over the row's per-block maxima; row r maps to first_cell + r, except a tail row (the last one,
+// when tail_cell >= 0) which maps to tail_cell.  n_blocks is a multiple of 8 and rows are 16-byte aligned.
+constexpr int CELLS_T = 1024;
+__global__ void __launch_bounds__(CELLS_T) k_aug_cells(const float* __restrict__ partial, unsigned n_blocks, int first_cell, int n_rows,
+                                                        int tail_cell, unsigned* __restrict__ cells) {
+    __shared__ float red[CELLS_T / 64];
+    const int r = blockIdx.x;
+    const float4* row = (const float4*)(partial + (size_t)r * n_blocks);
+    float v = 0.f;
+    for (unsigned i = threadIdx.x; i < n_blocks / 4; i += CELLS_T) {
+        float4 q = row[i];
+        v = fmaxf(fmaxf(v, fmaxf(q.x, q.y)), fmaxf(q.z, q.w));
+    }
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = red[0];
+        for (int i = 1; i < CELLS_T / 64; ++i) m = fmaxf(m, red[i]);
+        cells[(tail_cell >= 0 && r == n_rows - 1) ? tail_cell : first_cell + r] = __float_as_uint(m);
     }
 }
 
@@ -100,12 +153,14 @@ __device__ __forceinline__ float hash_u01(uint64_t index, unsigned seed) {
     return (float)((h >> 8) + 1u) * (1.0f / 16777216.0f);
 }
 
-struct Tri {   // trilinear footprint: corner indices (upper neighbour clamped) and fractions
-    int x0, x1, y0, y1, z0, z1;
+struct Tri {   // trilinear footprint: the 8 corner offsets (corner i: bit 0 = x, bit 1 = y, bit 2 = z; upper neighbours clamped), fractions
+    unsigned o[8];
     float tx, ty, tz;
     bool ok;
 };
 
+// 32-bit offsets inside one volume (launch_augment checks D*H*W < 2^31): the loads become base + 32-bit-offset accesses and the
+// address arithmetic stays off the quarter-rate 64-bit multiplier
 __device__ __forceinline__ Tri locate(float x, float y, float z, int W, int H, int D) {
     Tri t;
     // NaN positions (a distortion focus's own centre voxel, .cu:151: 0/0) fail these comparisons, as out-of-volume ones do
@@ -113,30 +168,33 @@ __device__ __forceinline__ Tri locate(float x, float y, float z, int W, int H, i
     if (!t.ok) return t;
     float fx = floorf(x), fy = floorf(y), fz = floorf(z);
     t.tx = x - fx; t.ty = y - fy; t.tz = z - fz;
-    t.x0 = (int)fx; t.y0 = (int)fy; t.z0 = (int)fz;
-    t.x1 = min(t.x0 + 1, W - 1); t.y1 = min(t.y0 + 1, H - 1); t.z1 = min(t.z0 + 1, D - 1);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1), z1 = min(z0 + 1, D - 1);
+    const unsigned r00 = (unsigned)(z0 * H + y0) * (unsigned)W, r10 = (unsigned)(z0 * H + y1) * (unsigned)W,
+                   r01 = (unsigned)(z1 * H + y0) * (unsigned)W, r11 = (unsigned)(z1 * H + y1) * (unsigned)W;
+    t.o[0] = r00 + x0; t.o[1] = r00 + x1; t.o[2] = r10 + x0; t.o[3] = r10 + x1;
+    t.o[4] = r01 + x0; t.o[5] = r01 + x1; t.o[6] = r11 + x0; t.o[7] = r11 + x1;
     return t;
 }
 
 __device__ __forceinline__ float lerp1(float t, float a, float b) { return a + t * (b - a); }
 
-template <typename F> __device__ __forceinline__ float trilinear(const Tri& t, F at) {
-    float c00 = lerp1(t.tx, at(t.x0, t.y0, t.z0), at(t.x1, t.y0, t.z0));
-    float c10 = lerp1(t.tx, at(t.x0, t.y1, t.z0), at(t.x1, t.y1, t.z0));
-    float c01 = lerp1(t.tx, at(t.x0, t.y0, t.z1), at(t.x1, t.y0, t.z1));
-    float c11 = lerp1(t.tx, at(t.x0, t.y1, t.z1), at(t.x1, t.y1, t.z1));
+__device__ __forceinline__ float trilinear(const Tri& t, const float* __restrict__ vol) {
+    float c00 = lerp1(t.tx, vol[t.o[0]], vol[t.o[1]]);
+    float c10 = lerp1(t.tx, vol[t.o[2]], vol[t.o[3]]);
+    float c01 = lerp1(t.tx, vol[t.o[4]], vol[t.o[5]]);
+    float c11 = lerp1(t.tx, vol[t.o[6]], vol[t.o[7]]);
     return lerp1(t.tz, lerp1(t.ty, c00, c10), lerp1(t.ty, c01, c11));
 }
 
 // label resampling for class ids: the value holding the largest total trilinear weight among the 8 corners
 // (first corner wins ties; corner order x fastest)
-template <typename F> __device__ __forceinline__ float majority(const Tri& t, F at) {
+__device__ __forceinline__ float majority(const Tri& t, const float* __restrict__ vol) {
     float v[8], w[8];
     float wx[2] = {1.0f - t.tx, t.tx}, wy[2] = {1.0f - t.ty, t.ty}, wz[2] = {1.0f - t.tz, t.tz};
-    int xs[2] = {t.x0, t.x1}, ys[2] = {t.y0, t.y1}, zs[2] = {t.z0, t.z1};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        v[i] = at(xs[i & 1], ys[(i >> 1) & 1], zs[i >> 2]);
+        v[i] = vol[t.o[i]];
         w[i] = wx[i & 1] * wy[(i >> 1) & 1] * wz[i >> 2];
     }
     float best = v[0], best_score = -1.f;
@@ -157,33 +215,25 @@ __device__ __forceinline__ void apply_affine(const UnetAugAffine& a, float& x, f
     x = nx; y = ny; z = nz;
 }
 
-__device__ __forceinline__ void voxel_xyz(int64_t i, const AugGeom& g, int& x, int& y, int& z) {
-    x = (int)(i % g.W);
-    int64_t r = i / g.W;
-    y = (int)(r % g.H);
-    z = (int)(r / g.H);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // dst (dw,dh,dd) <- trilinear resampling of src (sw,sh,sd): position = index * (source size / destination size)
 __global__ void __launch_bounds__(AUG_T) k_aug_scale(const float* __restrict__ src, float* __restrict__ dst, int sw, int sh,
                                                       int sd, int dw, int dh, int dd, float rx, float ry, float rz) {
-    int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
-    if (i >= (int64_t)dw * dh * dd) return;
-    int x = (int)(i % dw), y = (int)((i / dw) % dh), z = (int)(i / ((int64_t)dw * dh));
+    int x, y, z;
+    if (!row_voxel(dw, dh, x, y, z)) return;
+    const int64_t i = ((int64_t)z * dh + y) * dw + x;
     float px = fminf((float)x * rx, (float)(sw - 1)), py = fminf((float)y * ry, (float)(sh - 1)),
           pz = fminf((float)z * rz, (float)(sd - 1));
     Tri t = locate(px, py, pz, sw, sh, sd);
-    dst[i] = trilinear(t, [&](int a, int b, int c) { return src[((int64_t)c * sh + b) * sw + a]; });
+    dst[i] = trilinear(t, src);
 }
 
 __global__ void __launch_bounds__(AUG_T) k_aug_photo(AugGeom g, const AugTables* __restrict__ T, float* __restrict__ image,
                                                       float* __restrict__ label) {
     const AugPhoto& p = T->p;
-    int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
-    if (i >= g.N) return;
     int x, y, z;
-    voxel_xyz(i, g, x, y, z);
+    if (!row_voxel(g.W, g.H, x, y, z)) return;
+    const int64_t i = ((int64_t)z * g.H + y) * g.W + x;
     float lab = label[i];
     bool cropped = false;
     if (p.crop && lab != 0.f) {   // .cu:9-22
@@ -247,34 +297,28 @@ __device__ __forceinline__ void view_position(const AugView& a, int x, int y, in
 
 __global__ void __launch_bounds__(AUG_T) k_aug_view(AugGeom g, const AugTables* __restrict__ T, const float* __restrict__ image,
                                                      const float* __restrict__ label, float* __restrict__ out,
-                                                     float* __restrict__ out_label, unsigned* __restrict__ cells) {
+                                                     float* __restrict__ out_label, float* __restrict__ partial) {
     const AugView& a = T->a;
-    int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
-    bool live = i < g.N;
+    int x, y, z;
+    const bool live = brick_voxel(g, x, y, z);
+    const int64_t i = ((int64_t)z * g.H + y) * g.W + x;
     Tri t;
     t.ok = false;
     if (live) {
-        int x, y, z;
-        voxel_xyz(i, g, x, y, z);
         float px, py, pz;
         view_position(a, x, y, z, px, py, pz);
         t = locate(px, py, pz, g.W, g.H, g.D);
         float lab = 0.f;
-        if (t.ok) {
-            auto at = [&](int xx, int yy, int zz) { return label[((int64_t)zz * g.H + yy) * g.W + xx]; };
-            lab = a.is_label ? majority(t, at) : trilinear(t, at);
-        }
+        if (t.ok) lab = a.is_label ? majority(t, label) : trilinear(t, label);
         out_label[i] = lab;
     }
     for (int c = 0; c < g.C; ++c) {
         float v = 0.f;
         if (live && t.ok) {
-            const float* im = image + (int64_t)c * g.N;
-            v = trilinear(t, [&](int xx, int yy, int zz) { return im[((int64_t)zz * g.H + yy) * g.W + xx]; });
-            v = fmaxf(v, 0.f);   // lower_threshold, .cu:451
+            v = fmaxf(trilinear(t, image + (int64_t)c * g.N), 0.f);   // lower_threshold, .cu:451
         }
         if (live) out[(int64_t)c * g.N + i] = v;
-        block_max_to(cells + CELL_VIEW + c, v);
+        block_max_to(partial + (size_t)c * gridDim.x, v);
     }
 }
 
@@ -314,58 +358,64 @@ __device__ __forceinline__ float perlin_texture(const AugBg& b, const unsigned c
     return acc - floorf(acc);
 }
 
-// one rubber stamp: the labelled part of a pre-view channel, resampled through stamp s, clamped at 0 (.cu:472-475)
-__device__ __forceinline__ float stamp_value(const AugGeom& g, const UnetAugAffine& s, const float* __restrict__ im,
-                                             const float* __restrict__ label, int x, int y, int z) {
+// tipl::masking(image,label), .cu:469: the pre-view channels keep their labelled part only (in place, after the view pass
+// has read them), so that a stamp gathers one volume instead of two
+__global__ void __launch_bounds__(AUG_T) k_aug_mask(int64_t n, int channels, float* __restrict__ image, const float* __restrict__ label) {
+    int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
+    if (i >= n) return;
+    if (label[i] == 0.f)
+        for (int c = 0; c < channels; ++c) image[(int64_t)c * n + i] = 0.f;
+}
+
+// a rubber stamp = a masked pre-view channel resampled through stamp s and clamped at 0 (.cu:472-475)
+__device__ __forceinline__ Tri stamp_footprint(const AugGeom& g, const UnetAugAffine& s, int x, int y, int z) {
     float px = (float)x, py = (float)y, pz = (float)z;
     apply_affine(s, px, py, pz);
-    Tri t = locate(px, py, pz, g.W, g.H, g.D);
-    if (!t.ok) return 0.f;
-    float v = trilinear(t, [&](int xx, int yy, int zz) {
-        int64_t j = ((int64_t)zz * g.H + yy) * g.W + xx;
-        return label[j] != 0.f ? im[j] : 0.f;   // tipl::masking(image,label), .cu:469
-    });
-    return fmaxf(v, 0.f);
+    return locate(px, py, pz, g.W, g.H, g.D);
+}
+__device__ __forceinline__ float stamp_value(const Tri& t, const float* __restrict__ im) {
+    return t.ok ? fmaxf(trilinear(t, im), 0.f) : 0.f;
 }
 
 __global__ void __launch_bounds__(AUG_T) k_aug_bg_max(AugGeom g, const AugTables* __restrict__ T, const float* __restrict__ image,
-                                                       const float* __restrict__ label, unsigned* __restrict__ cells) {
+                                                       float* __restrict__ partial) {
     const AugBg& b = T->b;
     __shared__ unsigned char perm[512];
     for (int k = threadIdx.x; k < 512; k += AUG_T) perm[k] = b.perm[k];
     __syncthreads();
-    int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
-    bool live = i < g.N;
-    int x = 0, y = 0, z = 0;
-    if (live) voxel_xyz(i, g, x, y, z);
+    int x, y, z;
+    const bool live = brick_voxel(g, x, y, z);
     if (b.rubber)
-        for (int c = 0; c < g.C; ++c)
-            for (int s = 0; s < UNET_AUG_STAMPS; ++s) {
-                float v = live ? stamp_value(g, b.stamp[s], image + (int64_t)c * g.N, label, x, y, z) : 0.f;
-                block_max_to(cells + CELL_STAMP + c * UNET_AUG_STAMPS + s, v);
-            }
-    if (b.perlin) block_max_to(cells + CELL_PERLIN, live ? perlin_texture(b, perm, x, y, z) : 0.f);
+        for (int s = 0; s < UNET_AUG_STAMPS; ++s) {
+            Tri t;
+            t.ok = false;
+            if (live) t = stamp_footprint(g, b.stamp[s], x, y, z);
+            for (int c = 0; c < g.C; ++c)
+                block_max_to(partial + (size_t)(c * UNET_AUG_STAMPS + s) * gridDim.x, stamp_value(t, image + (int64_t)c * g.N));
+        }
+    if (b.perlin) block_max_to(partial + (size_t)(g.C * UNET_AUG_STAMPS) * gridDim.x, live ? perlin_texture(b, perm, x, y, z) : 0.f);
 }
 
 __device__ __forceinline__ float normalised(float v, float mx, float upper) { return mx > 0.f ? v / mx * upper : v; }
 
 __global__ void __launch_bounds__(AUG_T) k_aug_bg_blend(AugGeom g, const AugTables* __restrict__ T, const float* __restrict__ image,
-                                                         const float* __restrict__ label, float* __restrict__ out,
-                                                         const float* __restrict__ out_label, unsigned* __restrict__ cells) {
+                                                         float* __restrict__ out,
+                                                         const float* __restrict__ out_label, const unsigned* __restrict__ cells,
+                                                         float* __restrict__ partial) {
     const AugBg& b = T->b;
     __shared__ unsigned char perm[512];
     for (int k = threadIdx.x; k < 512; k += AUG_T) perm[k] = b.perm[k];
     __syncthreads();
-    int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
-    bool live = i < g.N;
-    int x = 0, y = 0, z = 0;
+    int x, y, z;
+    const bool live = brick_voxel(g, x, y, z);
+    const int64_t i = ((int64_t)z * g.H + y) * g.W + x;
     bool bgvox = false;
     float tex = 0.f;
     if (live) {
-        voxel_xyz(i, g, x, y, z);
         bgvox = out_label[i] == 0.f;   // blend_kernel .cu:191-198
         if (bgvox && b.perlin) tex = normalised(perlin_texture(b, perm, x, y, z), cell_value(cells, CELL_PERLIN), b.perlin_mag);
     }
+
     for (int c = 0; c < g.C; ++c) {
         float v = 0.f;
         if (live) {
@@ -374,7 +424,7 @@ __global__ void __launch_bounds__(AUG_T) k_aug_bg_blend(AugGeom g, const AugTabl
             if (bgvox) {
                 if (b.rubber)
                     for (int s = 0; s < UNET_AUG_STAMPS; ++s) {
-                        float bg = stamp_value(g, b.stamp[s], image + (int64_t)c * g.N, label, x, y, z);
+                        float bg = stamp_value(stamp_footprint(g, b.stamp[s], x, y, z), image + (int64_t)c * g.N);
                         bg = normalised(bg, cell_value(cells, CELL_STAMP + c * UNET_AUG_STAMPS + s), b.stamp_mag[c][s]);
                         v += bg * fmaxf(0.1f, 1.0f - v);
                     }
@@ -383,7 +433,7 @@ __global__ void __launch_bounds__(AUG_T) k_aug_bg_blend(AugGeom g, const AugTabl
             v = fmaxf(v, 0.f);   // .cu:517
             out[j] = v;
         }
-        block_max_to(cells + CELL_BLEND + c, v);
+        block_max_to(partial + (size_t)c * gridDim.x, v);
     }
 }
 
@@ -407,19 +457,32 @@ __global__ void __launch_bounds__(AUG_T) k_aug_final(AugGeom g, int mode, const 
 
 size_t aug_align(size_t v) { return (v + 255) / 256 * 256; }
 
+unsigned brick_grid(const UnetAugmentRecipe& r) {   // rounded up to a multiple of 8, see brick_voxel
+    int64_t b = (int64_t)((r.dims[0] + TX - 1) / TX) * ((r.dims[1] + TY - 1) / TY) * ((r.dims[2] + TZ - 1) / TZ);
+    return (unsigned)((b + 7) / 8 * 8);
+}
+size_t partial_floats(const UnetAugmentRecipe& r) { return (size_t)(r.channels * UNET_AUG_STAMPS + 1) * brick_grid(r); }
+
 }  // namespace
 
 size_t augment_scratch_bytes(const UnetAugmentRecipe& r) {
     size_t n = (size_t)r.dims[0] * r.dims[1] * r.dims[2];
     size_t low = r.downsample ? (size_t)r.low_dims[0] * r.low_dims[1] * r.low_dims[2] : 0;
     return aug_align(CELL_COUNT * sizeof(unsigned)) + aug_align(sizeof(AugTables)) + aug_align(n * sizeof(float) * r.channels) +
-           aug_align(n * sizeof(float)) + aug_align(low * sizeof(float));
+           aug_align(n * sizeof(float)) + aug_align(low * sizeof(float)) + aug_align(partial_floats(r) * sizeof(float));
 }
 
 // Host side of the reference's *_cuda wrappers: the constants they derive before launching (double where the reference's
 // expression is double, e.g. std::acos(-1)*0.5f/max, then rounded to the float kernel argument).
 void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void* scratch, hipStream_t st) {
-    AugGeom g{r.dims[0], r.dims[1], r.dims[2], r.channels, (int64_t)r.dims[0] * r.dims[1] * r.dims[2]};
+    AugGeom g{r.dims[0], r.dims[1], r.dims[2], r.channels, (int64_t)r.dims[0] * r.dims[1] * r.dims[2], 0, 0, 0};
+    g.gx = (g.W + TX - 1) / TX; g.gy = (g.H + TY - 1) / TY; g.gz = (g.D + TZ - 1) / TZ;
+    const int64_t bricks64 = (int64_t)g.gx * g.gy * g.gz;
+    if (bricks64 > (int64_t)1 << 30 || g.N >= (int64_t)1 << 31) throw std::runtime_error("unet_augment: volume too large (D*H*W must stay below 2^31)");
+    // ids are dealt to XCDs round-robin; rounding the grid up to a multiple of 8 keeps brick_voxel's renumbering onto
+    const unsigned bricks = brick_grid(r);
+    auto rows = [](int w, int h, int d) { return dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4), (unsigned)d); };
+    if (g.H > 4 * 65535 || g.D > 65535) throw std::runtime_error("unet_augment: height / depth beyond the launch grid");
     const int maxdim = std::max(r.dims[0], std::max(r.dims[1], r.dims[2]));
     char* base = (char*)scratch;
     unsigned* cells = (unsigned*)base;
@@ -431,17 +494,18 @@ void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void
     float* out_label = (float*)base;
     base += aug_align(g.N * sizeof(float));
     float* low = (float*)base;
+    base += aug_align((r.downsample ? (size_t)r.low_dims[0] * r.low_dims[1] * r.low_dims[2] : 0) * sizeof(float));
+    float* partial = (float*)base;
     if (hipMemsetAsync(cells, 0, CELL_COUNT * sizeof(unsigned), st) != hipSuccess) throw std::runtime_error("unet_augment: hipMemsetAsync failed");
     const unsigned nb = (unsigned)((g.N + AUG_T - 1) / AUG_T);
 
     if (r.downsample) {   // .cu:315-331: tipl::scale down and back up, per channel
         const int lw = r.low_dims[0], lh = r.low_dims[1], ld = r.low_dims[2];
-        const int64_t ln = (int64_t)lw * lh * ld;
         for (int c = 0; c < r.channels; ++c) {
             float* im = image + (int64_t)c * g.N;
-            k_aug_scale<<<(unsigned)((ln + AUG_T - 1) / AUG_T), AUG_T, 0, st>>>(im, low, g.W, g.H, g.D, lw, lh, ld, (float)g.W / (float)lw,
+            k_aug_scale<<<rows(lw, lh, ld), AUG_T, 0, st>>>(im, low, g.W, g.H, g.D, lw, lh, ld, (float)g.W / (float)lw,
                                                                               (float)g.H / (float)lh, (float)g.D / (float)ld);
-            k_aug_scale<<<nb, AUG_T, 0, st>>>(low, im, lw, lh, ld, g.W, g.H, g.D, (float)lw / (float)g.W, (float)lh / (float)g.H,
+            k_aug_scale<<<rows(g.W, g.H, g.D), AUG_T, 0, st>>>(low, im, lw, lh, ld, g.W, g.H, g.D, (float)lw / (float)g.W, (float)lh / (float)g.H,
                                               (float)ld / (float)g.D);
         }
     }
@@ -507,11 +571,19 @@ void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void
 
     k_aug_upload<<<1, 64, 0, st>>>(tables, tab);
     if (r.crop || r.trunc_top || r.trunc_bottom || r.noise || r.ambient || r.diffuse || r.specular)
-        k_aug_photo<<<nb, AUG_T, 0, st>>>(g, tab, image, label);
-    k_aug_view<<<nb, AUG_T, 0, st>>>(g, tab, image, label, out, out_label, cells);
+        k_aug_photo<<<rows(g.W, g.H, g.D), AUG_T, 0, st>>>(g, tab, image, label);
+    k_aug_view<<<bricks, AUG_T, 0, st>>>(g, tab, image, label, out, out_label, partial);
+    k_aug_cells<<<g.C, CELLS_T, 0, st>>>(partial, bricks, CELL_VIEW, g.C, -1, cells);
     if (mode == 2) {
-        k_aug_bg_max<<<nb, AUG_T, 0, st>>>(g, tab, image, label, cells);
-        k_aug_bg_blend<<<nb, AUG_T, 0, st>>>(g, tab, image, label, out, out_label, cells);
+        const int rows_bg = g.C * UNET_AUG_STAMPS + 1;
+        if (r.rubber) k_aug_mask<<<nb, AUG_T, 0, st>>>(g.N, g.C, image, label);
+        if (!(r.rubber && r.perlin) &&   // rows the pass does not write must read as 0
+            hipMemsetAsync(partial, 0, (size_t)rows_bg * bricks * sizeof(float), st) != hipSuccess)
+            throw std::runtime_error("unet_augment: hipMemsetAsync failed");
+        k_aug_bg_max<<<bricks, AUG_T, 0, st>>>(g, tab, image, partial);
+        k_aug_cells<<<rows_bg, CELLS_T, 0, st>>>(partial, bricks, CELL_STAMP, rows_bg, CELL_PERLIN, cells);
+        k_aug_bg_blend<<<bricks, AUG_T, 0, st>>>(g, tab, image, out, out_label, cells, partial);
+        k_aug_cells<<<g.C, CELLS_T, 0, st>>>(partial, bricks, CELL_BLEND, g.C, -1, cells);
     }
     k_aug_final<<<nb, AUG_T, 0, st>>>(g, mode, out, out_label, image, label, cells);
 }
