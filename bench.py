@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # BASELINE.json configs[4] (not the headline line): --size 256 --in-channels 2 --augment --no-cpu-baseline
+    ap.add_argument("--in-channels", type=int, default=1)
+    ap.add_argument("--augment", action="store_true", help="augment every sample on the GPU inside the timed step (unet_augment_run)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,14 +140,19 @@ def main():
 
     import unet_studio_amd as U
     n = a.size
-    model = U.UNet3d(1, 6, U.default_feature(6), device=dev, dtype=a.dtype, seed=0)
+    cin = a.in_channels
+    model = U.UNet3d(cin, 6, U.default_feature(6), device=dev, dtype=a.dtype, seed=0)
     if world > 1:  # same initial weights everywhere (the reference broadcasts every step: train.cpp:573-579)
         dist.broadcast(model.flat_params, 0)
     param = U.TrainingParam(batch_size=world, epoch=max(10000, a.steps + a.warmup + 1), learning_rate=0.001)
-    src = U.SyntheticVolumes(1, 6, (n, n, n), dev, cache=4)   # samples resident in HBM before the timed region
+    src = U.SyntheticVolumes(cin, 6, (n, n, n), dev, cache=4)   # samples resident in HBM before the timed region
     for i in range(world * 2):
         src(i % 4)
-    trainer = U.Trainer(model, param, lambda i: src(i % 4), rank, world)
+    feed = src
+    if a.augment:   # the resident template sample is augmented anew (seed = step-unique sample index) inside every timed step
+        aug = U.AugmentedVolumes(lambda i: src(i % 4))
+        feed = aug
+    trainer = U.Trainer(model, param, (lambda i: feed(i)) if a.augment else (lambda i: src(i % 4)), rank, world)
 
     def sync():
         if world > 1:
@@ -173,11 +181,13 @@ def main():
         kflops, ksec = dominant_kernel(U, n, a.dtype)
         peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32_MATRIX
         out = {
-            "metric": "voxels/sec 3D U-Net train step @128^3 bf16", "value": value, "unit": "voxels/s", "n_gpus": world,
+            "metric": "voxels/sec 3D U-Net train step @%d^3 %s" % (n, a.dtype), "value": value, "unit": "voxels/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": "configs[2]: train step (fwd+loss+bwd+clip+SGD-Nesterov), default UNet3d arch "
-                                   "(train.cpp:1054-1069), in=1 out=6, %d^3 volumes, 1 sample per GPU per step" % n,
+            "config": {"workload": "%s: train step (fwd+loss+bwd+clip+SGD-Nesterov), default UNet3d arch "
+                                   "(train.cpp:1054-1069), in=%d out=6, %d^3 volumes, 1 sample per GPU per step%s"
+                                   % ("configs[2]" if (cin, n, a.augment) == (1, 128, False) else "configs[4]-style" if a.augment else
+                                      "variant", cin, n, ", on-GPU visual_perception_augmentation inside the step" if a.augment else ""),
                        "global_batch": world, "volume": [n, n, n], "parallelism": "dp%d" % world,
                        "flops_per_step_per_sample": step_flops, "params": int(model.flat_params.numel())},
             "step_mfma_frac": (step_flops * world * a.steps / dt) / (peak * world),

@@ -56,9 +56,9 @@ def _compare(recipe, img, lab, is_label=True):
         assert same.mean() > 0.999, "label mismatch fraction %.5f" % (1 - same.mean())
     else:
         same = np.ones(ref_l.shape, bool)
-        assert np.abs(got_l - ref_l).max() < 2e-5
+        assert np.abs(got_l - ref_l).max() < 5e-6
     err = np.abs(got_i - ref_i)[:, same].max()
-    assert err < 2e-5, err      # images are in [0,1] after the normalisation
+    assert err < 5e-6, err      # images are in [0,1] after the normalisation; observed worst 4.2e-7 (profiles/augment_label_agreement.py)
     return got_i, got_l
 
 

@@ -1053,7 +1053,13 @@ int unet_augment_run(const UnetAugmentRecipe* recipe, float* image, float* label
     if (const char* e = augment_recipe_error(recipe)) return fail(e);
     if (!image || !label || !scratch) return fail("unet_augment_run: null device pointer");
     if (scratch_bytes < augment_scratch_bytes(*recipe)) return fail("unet_augment_run: scratch too small (see unet_augment_scratch_bytes)");
-    OP_TRY({ launch_augment(*recipe, image, label, scratch, (hipStream_t)stream); })
+    OP_TRY({
+        // the volumes' device is the one to launch on, whatever the calling thread's current device is
+        hipPointerAttribute_t at;
+        HIP_OK(hipPointerGetAttributes(&at, image));
+        DeviceGuard guard(at.device);
+        launch_augment(*recipe, image, label, scratch, (hipStream_t)stream);
+    })
 }
 
 }  // extern "C"

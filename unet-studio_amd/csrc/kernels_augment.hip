@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
+#include <string>
 
 #include "../../include/unet_augment.h"
 #include "kernels.h"
@@ -496,7 +497,8 @@ void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void
     float* low = (float*)base;
     base += aug_align((r.downsample ? (size_t)r.low_dims[0] * r.low_dims[1] * r.low_dims[2] : 0) * sizeof(float));
     float* partial = (float*)base;
-    if (hipMemsetAsync(cells, 0, CELL_COUNT * sizeof(unsigned), st) != hipSuccess) throw std::runtime_error("unet_augment: hipMemsetAsync failed");
+    if (hipError_t e = hipMemsetAsync(cells, 0, CELL_COUNT * sizeof(unsigned), st); e != hipSuccess)
+        throw std::runtime_error(std::string("unet_augment: hipMemsetAsync: ") + hipGetErrorString(e));
     const unsigned nb = (unsigned)((g.N + AUG_T - 1) / AUG_T);
 
     if (r.downsample) {   // .cu:315-331: tipl::scale down and back up, per channel
@@ -577,9 +579,9 @@ void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void
     if (mode == 2) {
         const int rows_bg = g.C * UNET_AUG_STAMPS + 1;
         if (r.rubber) k_aug_mask<<<nb, AUG_T, 0, st>>>(g.N, g.C, image, label);
-        if (!(r.rubber && r.perlin) &&   // rows the pass does not write must read as 0
-            hipMemsetAsync(partial, 0, (size_t)rows_bg * bricks * sizeof(float), st) != hipSuccess)
-            throw std::runtime_error("unet_augment: hipMemsetAsync failed");
+        if (!(r.rubber && r.perlin))   // rows the pass does not write must read as 0
+            if (hipError_t e = hipMemsetAsync(partial, 0, (size_t)rows_bg * bricks * sizeof(float), st); e != hipSuccess)
+                throw std::runtime_error(std::string("unet_augment: hipMemsetAsync: ") + hipGetErrorString(e));
         k_aug_bg_max<<<bricks, AUG_T, 0, st>>>(g, tab, image, partial);
         k_aug_cells<<<rows_bg, CELLS_T, 0, st>>>(partial, bricks, CELL_STAMP, rows_bg, CELL_PERLIN, cells);
         k_aug_bg_blend<<<bricks, AUG_T, 0, st>>>(g, tab, image, out, out_label, cells, partial);

@@ -18,6 +18,13 @@ if not os.path.exists(LIB_PATH):
         "libunet_hip.so not found at %s: build it first (python -c 'import __graft_entry__ as g; g.build()' "
         "or unet-studio_amd/csrc/build.sh); there is no CPU fallback" % LIB_PATH)
 
+# Load order matters: libunet_hip.so needs libamdhip64.so.7.  PyTorch-ROCm ships its own copy (torch/lib); when torch is loaded
+# first the dynamic linker resolves our dependency to that already-loaded runtime and the process has ONE HIP runtime that owns
+# both torch's allocations and our launches.  Loaded the other way round, /opt/rocm's copy comes in for us, torch brings its own,
+# and the second runtime finds no device ("no ROCm-capable device is detected", profiles/hip_runtime_load_order.py).  torch is the
+# allocator / stream provider of every caller of this module, so it is imported here, before the library.
+import torch  # noqa: E402,F401
+
 lib = C.CDLL(LIB_PATH)
 
 _vp, _i, _sz, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_float
@@ -155,6 +162,6 @@ class Plan:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h is not None and h.value:
+        if h is not None and h.value and lib is not None:   # `lib` is None once the interpreter tears the module down
             lib.unet_plan_destroy(h)
             self.handle = C.c_void_p()
