@@ -483,3 +483,69 @@ def test_full_size_128_properties(dt):
     fd = (lp - lm) / (2 * eps)
     an = float((g1 * dvec).sum())
     assert abs(fd - an) < 0.25 * max(abs(an), 1e-3), (fd, an)
+
+
+# ---- the two forward-only callers of the path: evaluate.cpp:211-246 (a22) and the validation thread train.cpp:826-852 (a23) ----
+ARCH_BN_EVAL = ("conv8,ks3,stride1+bnorm,relu+conv8,ks3,stride1+bnorm,relu\n"
+                "max_pool+conv16,ks3,stride1+bnorm,relu+conv16,ks3,stride1+bnorm,relu+conv_trans8,ks2,stride2\n"
+                "conv8,ks3,stride1+bnorm,relu+conv8,ks3,stride1+bnorm,relu+conv6,ks1,stride1")
+
+
+def _trained_bn_pair(dt):
+    """engine model + ATen module with the same weights and the same non-trivial running statistics (two train forwards)."""
+    torch.manual_seed(5)
+    ref = A.UNet3dRef(2, 6, ARCH_BN_EVAL)
+    ref.train()
+    m = U.UNet3d(2, 6, ARCH_BN_EVAL, device=DEV, dtype=dt)
+    m.load_parameters([p.detach().numpy() for p in ref.parameters()])
+    m.train()
+    for s in range(2):
+        x, _ = A.synthetic_sample(2, 6, (16, 24, 32), 20 + s)
+        with torch.no_grad():
+            ref(x)
+        m.forward(x.to(DEV))
+    return m, ref
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_validation_forward_keeps_running_statistics(dt):
+    """train.cpp:834-852: eval() without prepare_for_inference -> bnorm uses the running statistics; mean (ce, dice, mse) of
+    calc_losses on output [0] over the test volumes, appended to testing_errors."""
+    m, ref = _trained_bn_pair(dt)
+    vols = [A.synthetic_sample(2, 6, (16, 24, 32), 40 + i) for i in range(2)]
+    ref.eval()
+    exp = np.zeros(3)
+    with torch.no_grad():
+        for x, t in vols:
+            ce, dice, mse = A.calc_losses(ref(x)[0], t, 6)
+            exp += np.array([float(ce), float(dice), float(mse)])
+    exp /= len(vols)
+    tr = U.Trainer(m, U.TrainingParam(batch_size=1, epoch=10), lambda i: None)
+    got = tr.validate([x.to(DEV) for x, _ in vols], [t.to(DEV) for _, t in vols])
+    tol = 2e-4 if dt == "fp32" else 3e-2
+    assert np.allclose(got, exp, rtol=tol, atol=tol * 0.1), (got, exp)
+    assert m.get_testing_errors() == got and m._training      # recorded; training mode restored for thread C
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_evaluate_loop_matches_the_reference_inference(dt):
+    """evaluate.cpp:386-399,211-246: prepare_for_inference (running statistics reset: bnorm = gamma*x+beta), forward [0],
+    host buffer (in*D,H,W) -> (out*D,H,W)."""
+    m, ref = _trained_bn_pair(dt)
+    ios = [[A.synthetic_sample(2, 6, (16, 24, 32), 60 + i)[0][0].reshape(2 * 16, 24, 32).numpy()] for i in range(2)]
+    ios[1].append(A.synthetic_sample(2, 6, (8, 16, 40), 70)[0][0].reshape(2 * 8, 16, 40).numpy())   # a second size in one file
+    ev = U.EvaluateUNet(m)
+    out = ev.start(ios)
+    assert not ev.aborted and ev.error_msg == "" and ev.cur_prog == 2
+    ref.prepare_for_inference()
+    tol = 2e-4 if dt == "fp32" else 4e-2
+    for a, b in zip(ios, out):
+        for io, res in zip(a, b):
+            d = io.shape[0] // 2
+            with torch.no_grad():
+                e = ref(torch.from_numpy(io).view(1, 2, d, io.shape[1], io.shape[2]))[0][0].numpy()
+            assert res.shape == (6 * d, io.shape[1], io.shape[2]) and res.dtype == np.float32
+            assert rel(torch.from_numpy(res.reshape(e.shape)), torch.from_numpy(e)) < tol
+    # an input the network cannot take ends the run the reference's way: message + aborted, no exception (evaluate.cpp:234-242)
+    bad = ev.start([[np.zeros((2 * 5, 24, 32), np.float32)]])
+    assert ev.aborted and ev.error_msg.startswith("error during evaluation:") and ev.cur_prog == 0

@@ -8,6 +8,7 @@ from .engine import DTYPE_BF16, DTYPE_F32, IMPL_AUTO, IMPL_DIRECT, Plan, UNetErr
 from .unet3d import SGD, UNet3d  # noqa: F401
 from .train import SyntheticVolumes, Trainer, TrainingParam  # noqa: F401
 from . import augment  # noqa: F401
+from .evaluate import EvaluateUNet  # noqa: F401
 from .augment import AugmentedVolumes, visual_perception_augmentation  # noqa: F401
 
 

@@ -97,6 +97,27 @@ class Trainer:
         self.cur_epoch += 1
         return self._stats
 
+    def validate(self, test_in, test_out, output_model=None):
+        """Thread D's body for one epoch (train.cpp:834-852, 890-895): eval() WITHOUT the running-statistics reset of
+        prepare_for_inference (a bnorm model normalises with its running statistics here), forward, calc_losses on
+        the full-resolution output only, mean over the test volumes -> [ce, dice, mse], appended to testing_errors."""
+        m = output_model if output_model is not None else self.model
+        was_training = m._training
+        m.eval()
+        acc = torch.zeros(3, dtype=torch.float64)
+        with torch.no_grad():
+            for x, t in zip(test_in, test_out):
+                outs = m.forward(x)
+                # unet_loss reports the full-resolution level's unweighted (ce, dice, mse) in slots 1..3: calc_losses(forward(x)[0], ...)
+                losses, _ = m.loss(outs, t, True, True, True, 0, want_grad=False)
+                acc += losses[1:4].double().cpu()
+        m.train(was_training)
+        errors = (acc / max(1, len(test_in))).tolist() if len(test_in) else []
+        with self.model.error_mutex:
+            for mm in {id(self.model): self.model, id(m): m}.values():
+                mm.testing_errors.extend(errors)
+        return errors
+
     def record_errors(self):
         """train.cpp:743-752: append the step's mean (ce, dice, mse) -- a host sync, call it sparingly"""
         e = (self._stats[1:4] / float(self.param.batch_size)).tolist()
