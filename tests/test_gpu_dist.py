@@ -58,7 +58,9 @@ def test_two_rank_gpu_step_equals_single_rank(dtype):
     assert np.array_equal(p0, p1), "ranks diverged: the update is not identical on every rank"
     ref, sref = single[0]
     # the two-rank sum adds the micro-step gradients in a different order than the single buffer does: fp32 rounding only
-    tol = 1e-5 if dtype == "fp32" else 1e-4
+    # (measured: 4 of 74116 parameters differ by more than 1e-5 after three steps, the largest by 1.35e-5 --
+    # profiles/dbg_f32_determinism.py; each run by itself is bit-reproducible)
+    tol = 5e-5 if dtype == "fp32" else 1e-4
     assert np.allclose(p0, ref, rtol=tol, atol=tol)
     assert np.allclose(s0, sref, rtol=1e-4, atol=1e-5)
     assert np.allclose(s0, s1)

@@ -66,6 +66,8 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     (32, 3, (5, 6, 7), 1, 1), (16, 8, (33, 8, 9), 1, 1),
     # small-volume MFMA kernel: 8 chunks (two per wave, fragment refill), 16 chunks (two super-stages), 4^3 tile
     (256, 16, (8, 8, 8), 3, 1), (512, 32, (5, 6, 7), 3, 1), (256, 32, (4, 4, 4), 3, 1), (96, 32, (3, 4, 10), 3, 1),
+    # fp32 matrix-core conv (fp32 engine, volumes >= 4096 voxels): NT 1 / 2, ragged tile edges in z, y and x, 8-channel chunk tail
+    (16, 16, (16, 16, 32), 3, 1), (32, 64, (17, 19, 21), 3, 1), (24, 48, (9, 23, 22), 3, 1), (64, 32, (18, 17, 16), 3, 1),
 ]
 
 
@@ -297,7 +299,10 @@ def test_default_arch_fp32_against_golden(golden_dir, size):
     m._run_backward(plan, ws, gouts)
     gl2 = np.array([float(g.double().norm()) for g in m.grads()])
     big = d["grad_l2"] > 1e-3 * d["grad_l2"].max()   # conv biases before a norm have analytically zero gradient
-    assert np.allclose(gl2[big], d["grad_l2"][big], rtol=2e-3)
+    # 2e-3 relative, plus 2e-4 of the largest norm for the small ones: a leaky_relu voxel on its kink takes another slope when the
+    # forward convs sum in another order (the fp32 matrix-core kernel) -- see test_noncubic_network_against_live_aten, whose elu twin
+    # shows the engine itself at 5e-7 of fp64 gradients
+    assert np.allclose(gl2[big], d["grad_l2"][big], rtol=2e-3, atol=2e-4 * float(d["grad_l2"].max()))
     heads = np.stack([np.pad(g.flatten()[:16].cpu().numpy(), (0, max(0, 16 - g.numel()))) for g in m.grads()])
     assert rel(heads[big], d["grad_head"][big]) < 2e-3
 
@@ -346,37 +351,44 @@ ARCH_MIX_NC = ("conv8,ks3,stride1+norm,elu+conv8,ks3,stride1+norm,leaky_relu\n"
 @pytest.mark.parametrize("size", [(24, 40, 56), (20, 36, 12), (8, 16, 132), (12, 20, 28, "mix")])
 def test_noncubic_network_against_live_aten(size, dt):
     """volumes that are not cubes and not multiples of any tile (ragged sliding-window columns, partial planes, W < 16, long rows):
-    forward, loss and backward against the ATen CPU executor run live IN FLOAT64 (oracle/aten_ref.py).  fp64 because the deepest
-    level normalises over as few as 5 x 9 x 3 voxels: there ATen's own fp32 gradients are 3e-3 away from its fp64 ones."""
+    forward, loss and backward against the ATen CPU executor run live IN FLOAT64 (oracle/aten_ref.py).
+
+    Gradients and the kink of leaky_relu / relu: a voxel whose normalised value lies within rounding distance of 0 takes slope 1 in
+    one fp32 evaluation and 0.01 in another.  One such voxel moves the weight gradients around it by ~1e-3 of the largest gradient
+    (profiles/dbg_grad_error.py: 7e-3 at (20,36,12), 3e-3 at (16,16,36), nothing at (16,16,40); the same digits with every kernel
+    variant, with fp32 or fp64 statistics).  With the smooth activation (elu) in the same places the fp32 engine is within 5e-7 of the
+    fp64 gradients on every size -- so the fp32 engine is checked twice: the architecture as given with a kink-tolerant bound, and
+    its elu twin at fp32 resolution."""
     arch = ARCH_NONCUBIC
     if len(size) == 4:   # every other layer kind (elu / relu, max_pool, upsample, 8-channel convs on the direct kernels)
         arch, size = ARCH_MIX_NC, size[:3]
-    torch.manual_seed(3)
-    ref = A.UNet3dRef(2, 5, arch)
-    ref.train()
-    x, t = A.synthetic_sample(2, 5, size, 11)
-    m = U.UNet3d(2, 5, arch, device=DEV, dtype=dt)
-    m.load_parameters([p.detach().numpy() for p in ref.parameters()])
-    ref = ref.double()
-    outs_ref = ref(x.double())
-    loss_ref, _ = A.deep_supervision_loss(outs_ref, t, 5)
-    loss_ref.backward()
-    xd, td = x.to(DEV), t.to(DEV)
-    plan = m.plan_for(xd.shape[2:]); ws = m._workspace(plan)
-    outs = m._run_forward(plan, ws, xd, 1)
-    for k, (o, r) in enumerate(zip(outs, outs_ref)):
-        e = rel(o[0].cpu().numpy().astype(np.float64), r[0].detach().numpy())
-        assert e < (1e-4 if dt == "fp32" else 8e-2), "logits level %d: %g" % (k, e)
-    losses, gouts = m.loss(outs, td)
-    assert abs(float(losses[0]) - float(loss_ref)) < (1e-4 if dt == "fp32" else 2e-2) * float(loss_ref)
-    m._run_backward(plan, ws, gouts)
-    gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).numpy()
-    g = m.flat_grads.cpu().numpy().astype(np.float64)
-    e = np.abs(g - gref).max() / np.abs(gref).max()
-    # fp32 engine: measured 5.5e-4 of the largest gradient on the first size (ATen fp32: 1e-6) -- its norm statistics are
-    # E[x^2] - mean^2 from fp32 block partials and the weight gradient of a conv behind a norm is a sum that cancels to ~1e-3 of its
-    # terms; on the two sizes with tiny deep levels even ATen's fp32 gradients are 3e-3 from its fp64 ones
-    assert e < (5e-3 if dt == "fp32" else 1.5e-1), "gradients: %g" % e
+    variants = [(arch, 1e-2 if dt == "fp32" else 1.5e-1)]
+    if dt == "fp32":
+        variants.append((arch.replace("leaky_relu", "elu").replace(",relu", ",elu"), 5e-6))
+    for arch_v, grad_bound in variants:
+        torch.manual_seed(3)
+        ref = A.UNet3dRef(2, 5, arch_v)
+        ref.train()
+        x, t = A.synthetic_sample(2, 5, size, 11)
+        m = U.UNet3d(2, 5, arch_v, device=DEV, dtype=dt)
+        m.load_parameters([p.detach().numpy() for p in ref.parameters()])
+        ref = ref.double()
+        outs_ref = ref(x.double())
+        loss_ref, _ = A.deep_supervision_loss(outs_ref, t, 5)
+        loss_ref.backward()
+        xd, td = x.to(DEV), t.to(DEV)
+        plan = m.plan_for(xd.shape[2:]); ws = m._workspace(plan)
+        outs = m._run_forward(plan, ws, xd, 1)
+        for k, (o, r) in enumerate(zip(outs, outs_ref)):
+            e = rel(o[0].cpu().numpy().astype(np.float64), r[0].detach().numpy())
+            assert e < (1e-4 if dt == "fp32" else 8e-2), "logits level %d: %g" % (k, e)
+        losses, gouts = m.loss(outs, td)
+        assert abs(float(losses[0]) - float(loss_ref)) < (1e-4 if dt == "fp32" else 2e-2) * float(loss_ref)
+        m._run_backward(plan, ws, gouts)
+        gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).numpy()
+        g = m.flat_grads.cpu().numpy().astype(np.float64)
+        e = np.abs(g - gref).max() / np.abs(gref).max()
+        assert e < grad_bound, "gradients (%s): %g" % ("as given" if arch_v is arch else "elu twin", e)
 
 
 def test_backward_in_buckets_equals_one_backward():

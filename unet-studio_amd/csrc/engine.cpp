@@ -112,7 +112,7 @@ struct unet_plan {
         for (size_t i = 0; i < g.norms.size(); ++i) {
             n_stat[i] = take(4 * (size_t)g.norms[i].C * 4);
             n_coef[i] = take(3 * (size_t)g.norms[i].C * 4);
-            size_t pb = (size_t)stats_blocks(g.tensors[g.norms[i].tensor].voxels()) * g.norms[i].C * 2 * 4;
+            size_t pb = (size_t)stats_blocks(g.tensors[g.norms[i].tensor].voxels()) * g.norms[i].C * 2 * (dtype == UNET_DTYPE_F32 ? 8 : 4);
             if (pb > pmax) pmax = pb;
         }
         w_fwd.assign(g.ops.size(), SIZE_MAX); w_dgrad.assign(g.ops.size(), SIZE_MAX);
@@ -335,6 +335,11 @@ struct Exec {
                                                           want_stats ? partial() : nullptr, s);
                         if (want_stats) fused_blocks[T.norm] = rows;
                         if (mode == 1) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                    } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level < 0 &&
+                               conv_f32_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
+                        // fp32 engine: the same IEEE fp32 products and sums as the VALU kernel below, on the fp32 matrix cores
+                        launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                        launch_conv_f32_mfma(cg, sd, op.nsrc, wf, params[op.bias], (float*)tptr(op.dst), s);
                     } else if (op.kind == OP_CONV) {
                         launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
@@ -356,13 +361,15 @@ struct Exec {
                                          stat(op.norm), s);
                     } else {
                         int nb = fused_blocks[op.norm];
+                        bool dbl = false;   // fp32 tensors leave fp64 block partials (k_stats_partial)
                         if (!nb) {
                             launch_stats_partial(p.dtype, tptr(n.tensor), n.C, T.voxels(), partial(), s);
                             nb = stats_blocks(T.voxels());
+                            dbl = p.dtype == UNET_DTYPE_F32;
                         }
                         launch_norm_finalize(partial(), nb, n.C, T.voxels(), params[n.gamma], params[n.beta],
                                              n.eps, stat(op.norm), n.batch ? buffers[n.buffer] : nullptr,
-                                             n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, s);
+                                             n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, s, dbl);
                     }
                     apply_view(n.tensor);
                     break;
@@ -403,7 +410,7 @@ struct Exec {
             const Norm& n = p.g.norms[T.norm];
             launch_norm_bwd_partial(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), T.act, partial(), s);
             launch_norm_bwd_finalize(partial(), stats_blocks(T.voxels()), T.C, T.voxels(), params[n.gamma], stat(T.norm), coef(T.norm),
-                                     gparams[n.gamma], gparams[n.beta], s);
+                                     gparams[n.gamma], gparams[n.beta], s, p.dtype == UNET_DTYPE_F32);
             launch_norm_bwd_apply(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), coef(T.norm), T.act, s);
         } else if (T.act != ACT_NONE) {
             launch_act_bwd(p.dtype, gptr(t), tptr(t), T.act, T.numel(), s);
@@ -828,7 +835,7 @@ int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes)
     if (D > 0 && H > 0 && W > 0) {   // statistics partials of unet_op_conv3d_fwd_fused, behind the filter packs
         int64_t S = (int64_t)D * H * W;
         size_t blocks = (size_t)(S / 32 + 4096);   // >= any conv tile count (>= 64 voxels per tile, ragged edges) and >= stats_blocks(S)
-        b += align_up(blocks * cout * 2 * 4);
+        b += align_up(blocks * cout * 2 * 8);   // fp64 partials for fp32 tensors
     }
     if ((int64_t)cin * cout <= 1024) {   // small-weight wgrad slabs: <= 1024 row blocks x <= 1024 weights, + bias partials
         size_t w = ((size_t)1024 * 1024 + (size_t)1024 * cout) * 4 + 1024;
@@ -887,7 +894,8 @@ int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const
             launch_conv_first_mfma(g, &sd, w, b, y, nullptr, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
-            launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+            if (impl == UNET_IMPL_AUTO && conv_f32_mfma_supported(dtype, g, &sd, 1)) launch_conv_f32_mfma(g, &sd, 1, wf, b, (float*)y, s);
+            else launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
         }
     })
 }
@@ -913,10 +921,11 @@ int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* sc
             if (stats) launch_stats_sum(part, rows, cout, stats, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
-            launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+            if (impl == UNET_IMPL_AUTO && conv_f32_mfma_supported(dtype, g, &sd, 1)) launch_conv_f32_mfma(g, &sd, 1, wf, b, (float*)y, s);
+            else launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
             if (stats) {
                 launch_stats_partial(dtype, y, cout, So, part, s);
-                launch_stats_sum(part, stats_blocks(So), cout, stats, s);
+                launch_stats_sum(part, stats_blocks(So), cout, stats, s, dtype == UNET_DTYPE_F32);
             }
         }
     })

@@ -66,13 +66,14 @@ void launch_convt_wgrad_direct(int dtype, const ConvGeom& g, const SrcDesc* src,
 // number of partial blocks the statistics kernels use for S voxels (plan-time constant)
 int stats_blocks(int64_t S);
 // per-block partial {sum, sumsq} of a raw tensor: partial[blk][c][2]
+// block partials: float for bf16 tensors, DOUBLE for fp32 tensors (then pass dbl = true to the finalize / sum that reads them)
 void launch_stats_partial(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s);
 // partials -> stat[0..C) mean, [C..2C) rstd, [2C..3C) scale = gamma*rstd, [3C..4C) shift = beta - mean*scale;
 // running stats (bnorm, may be nullptr): rm = (1-m)*rm + m*mean, rv = (1-m)*rv + m*unbiased var
 void launch_norm_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
-                          float* stat, float* running_mean, float* running_var, double momentum, hipStream_t s);
+                          float* stat, float* running_mean, float* running_var, double momentum, hipStream_t s, bool dbl = false);
 // partials -> out[c][2] = {sum, sum of squares}
-void launch_stats_sum(const float* partial, int nblk, int C, float* out, hipStream_t s);
+void launch_stats_sum(const float* partial, int nblk, int C, float* out, hipStream_t s, bool dbl = false);
 // eval-mode bnorm: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (mean := rm, rstd := 1/sqrt(rv+eps))
 void launch_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat,
                       hipStream_t s);
@@ -85,7 +86,7 @@ void launch_norm_bwd_partial(int dtype, void* g, const void* u, int C, int64_t S
                              hipStream_t s);
 // pass 2: coef[0..C) = gamma*rstd, [C..2C) = mean(dv), [2C..3C) = mean(dv*xhat); dgamma += sum dv*xhat, dbeta += sum dv
 void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat, float* coef,
-                              float* dgamma, float* dbeta, hipStream_t s);
+                              float* dgamma, float* dbeta, hipStream_t s, bool dbl = false);
 // pass 3: g <- du = coef0 * (dv - m1 - xhat*m2)
 void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, int act,
                            hipStream_t s);
@@ -183,6 +184,11 @@ size_t mfma_convt_dgrad_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_convt_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
 void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s);
 void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
+
+// kernels_mfma_f32.hip: fp32 3x3x3 stride-1 conv on the fp32 matrix cores (the fp32 engine with impl == AUTO)
+bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
+                          hipStream_t s);
 
 // kernels_augment.hip: on-GPU sample augmentation (include/unet_augment.h)
 size_t augment_scratch_bytes(const UnetAugmentRecipe& r);

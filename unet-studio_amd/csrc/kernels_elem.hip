@@ -63,32 +63,42 @@ int stats_blocks(int64_t S) {
 }
 static inline int pow2_ge(int c) { int p = 1; while (p < c && p < 256) p <<= 1; return p; }
 
+// Accumulator of the statistics kernels: fp32 tensors (the fp32 engine = the parity configuration) are summed in fp64 and leave
+// fp64 block partials, as ATen's CPU norm kernels do (acc_type<float> is double there).  The sums cancel -- sum dv*xhat of the
+// norm backward is a projection residue, E[x^2]-mean^2 a difference of near-equal numbers when the mean dwarfs the spread --
+// and with fp32 sums the weight gradients behind a norm were 3e-3 of the largest gradient away from an fp64 evaluation.
+template <typename T> struct StatAcc { typedef float type; };
+template <> struct StatAcc<float> { typedef double type; };
+
 // MODE 0: {sum x, sum x^2};  MODE 1 (norm backward): g <- dv = g*act'(v); {sum dv, sum dv*xhat}
+// partial: [block][C][2] of StatAcc<T>::type (float for bf16 tensors, double for fp32 tensors)
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) k_stats_partial(const T* __restrict__ x, T* __restrict__ gbuf, int C, int64_t S, int64_t VPB,
-                                                       int CW, const float* __restrict__ stat, int act, float* __restrict__ partial) {
-    __shared__ float red[2][256];
+                                                       int CW, const float* __restrict__ stat, int act, float* __restrict__ partial_) {
+    typedef typename StatAcc<T>::type A;
+    A* partial = (A*)partial_;
+    __shared__ A red[2][256];
     int NV = 256 / CW, cl = threadIdx.x % CW, lane = threadIdx.x / CW;
     int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
     for (int cg = 0; cg < C; cg += CW) {
         int c = cg + cl;
-        float s1 = 0.f, s2 = 0.f;
+        A s1 = 0, s2 = 0;
         if (c < C) {
             float mean = 0.f, rstd = 1.f, sc = 1.f, sh = 0.f;
             if (MODE == 1) { mean = stat[c]; rstd = stat[C + c]; sc = stat[2 * C + c]; sh = stat[3 * C + c]; }
             for (int64_t v = v0 + lane; v < v1; v += NV) {
                 float u = ld<T>(x, v * C + c);
-                if (MODE == 0) { s1 += u; s2 = fmaf(u, u, s2); }
+                if (MODE == 0) { s1 += (A)u; s2 += (A)u * (A)u; }
                 else {   // dv is not stored: the apply pass recomputes it from the same inputs
                     float dv = ld<T>(gbuf, v * C + c) * act_d(fmaf(u, sc, sh), act);
-                    s1 += dv; s2 = fmaf(dv, (u - mean) * rstd, s2);
+                    s1 += (A)dv; s2 += (A)dv * (A)((u - mean) * rstd);
                 }
             }
         }
         red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
         __syncthreads();
         if (lane == 0 && c < C) {
-            float a = 0.f, b = 0.f;
+            A a = 0, b = 0;
             for (int l = 0; l < NV; ++l) { a += red[0][l * CW + cl]; b += red[1][l * CW + cl]; }
             partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = a;
             partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
@@ -222,12 +232,23 @@ __device__ __forceinline__ void reduce2_wave(double& a, double& b) {
 }
 
 // one wave per channel
+// block partials [blk][C][2]: float, or (dbl) double as k_stats_partial leaves them for fp32 tensors
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partial, int dbl, int nblk, int C, int c, double& a, double& b) {
+    a = 0.0; b = 0.0;
+    if (dbl) {
+        const double* pd = (const double*)partial;
+        for (int i = threadIdx.x; i < nblk; i += 64) { a += pd[((int64_t)i * C + c) * 2]; b += pd[((int64_t)i * C + c) * 2 + 1]; }
+    } else {
+        for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+    }
+}
+
 __global__ void __launch_bounds__(64) k_norm_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
                                                       const float* gamma, const float* beta, double eps, float* stat, float* rm,
-                                                      float* rv, double momentum) {
+                                                      float* rv, double momentum, int dbl) {
     int c = blockIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+    double a, b;
+    sum_partials(partial, dbl, nblk, C, c, a, b);
     reduce2_wave(a, b);
     if (threadIdx.x == 0) {
         double mean = a / (double)S, var = b / (double)S - mean * mean;
@@ -242,19 +263,21 @@ __global__ void __launch_bounds__(64) k_norm_finalize(const float* __restrict__ 
     }
 }
 void launch_norm_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
-                          float* stat, float* rm, float* rv, double momentum, hipStream_t s) {
-    k_norm_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, beta, eps, stat, rm, rv, momentum);
+                          float* stat, float* rm, float* rv, double momentum, hipStream_t s, bool dbl) {
+    k_norm_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, beta, eps, stat, rm, rv, momentum, dbl ? 1 : 0);
 }
 
 // out[c][j] = sum over blocks of partial[blk][c][j]   (one wave per channel, fp64, fixed order)
-__global__ void __launch_bounds__(64) k_stats_sum(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_stats_sum(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int dbl) {
     int c = blockIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+    double a, b;
+    sum_partials(partial, dbl, nblk, C, c, a, b);
     reduce2_wave(a, b);
     if (threadIdx.x == 0) { out[c * 2] = (float)a; out[c * 2 + 1] = (float)b; }
 }
-void launch_stats_sum(const float* partial, int nblk, int C, float* out, hipStream_t s) { k_stats_sum<<<C, 64, 0, s>>>(partial, nblk, C, out); }
+void launch_stats_sum(const float* partial, int nblk, int C, float* out, hipStream_t s, bool dbl) {
+    k_stats_sum<<<C, 64, 0, s>>>(partial, nblk, C, out, dbl ? 1 : 0);
+}
 
 __global__ void k_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat) {
     int c = blockIdx.x * 64 + threadIdx.x;
@@ -269,10 +292,10 @@ void launch_norm_eval(int C, const float* gamma, const float* beta, const float*
 
 __global__ void __launch_bounds__(64) k_norm_bwd_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
                                                           const float* gamma, const float* stat, float* coef, float* dgamma,
-                                                          float* dbeta) {
+                                                          float* dbeta, int dbl) {
     int c = blockIdx.x;
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+    double a, b;
+    sum_partials(partial, dbl, nblk, C, c, a, b);
     reduce2_wave(a, b);
     if (threadIdx.x == 0) {
         coef[c] = gamma[c] * stat[C + c];
@@ -283,8 +306,8 @@ __global__ void __launch_bounds__(64) k_norm_bwd_finalize(const float* __restric
     }
 }
 void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat, float* coef,
-                              float* dgamma, float* dbeta, hipStream_t s) {
-    k_norm_bwd_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, stat, coef, dgamma, dbeta);
+                              float* dgamma, float* dbeta, hipStream_t s, bool dbl) {
+    k_norm_bwd_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, stat, coef, dgamma, dbeta, dbl ? 1 : 0);
 }
 
 template <typename T> __global__ void k_norm_bwd_apply(T* __restrict__ g, const T* __restrict__ u, int C, int64_t n,

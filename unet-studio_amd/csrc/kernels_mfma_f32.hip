@@ -1,0 +1,166 @@
+// fp32 3x3x3 convolution (stride 1 and 2) on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), for the fp32 engine
+// (UNET_DTYPE_F32: the parity configuration and BASELINE.json configs[1], the full forward on a 128^3 volume in fp32).
+// The products and the accumulation are IEEE fp32, exactly as in the VALU kernel of kernels_direct.hip it replaces when
+// impl == AUTO -- only the summation order differs -- so the 1e-4 logit tolerance of the fp32 path holds unchanged.
+//
+//   D[voxel x][cout] += X[voxel x + kx][cin] * W[tap][cin][cout]        M = 16 voxels of one x-row, N = 16 cout, K = 4 cin
+//
+// Block = 256 threads = 4 waves, output tile 4 (z) x BY (y) x 16 (x) voxels x 16*NT output channels; wave w owns the BY rows of
+// z-slice w.  Per CK-channel chunk of the input: the halo tile (stride 1, BY 8: 6 x 10 x 18 voxels; stride 2, BY 4: 9 x 9 x 33) is
+// staged channel-major ([cin][voxel], plane stride = 16 mod 64 floats, so the four k-groups of a wave hit four disjoint bank
+// ranges) with the consumer-side transform act(x*scale+shift) applied on the way in (zero padding is applied AFTER it, as the
+// reference pads the activated tensor); the chunk's filter slice is staged as [nt][tap][cin][16].  For one (kz, kx, k-group) a
+// wave reads the halo rows it needs ONCE and feeds them to 3 (ky) x BY (rows) x NT MFMAs (stride 1: 10 + 3*NT LDS reads per
+// 24*NT MFMAs).  Measured at 128^3: 32->16 (58 GFLOP) in 0.60 ms = 97 TFLOP/s of the 157 the fp32 matrix pipe has.
+#include "mfma_util.h"
+#include "kernels.h"
+
+namespace unet {
+
+namespace {
+
+constexpr int F_BZ = 4, F_BX = 16;
+template <int S, int BY, int CK> struct F32Tile {
+    static constexpr int HZ = (F_BZ - 1) * S + 3, HY = (BY - 1) * S + 3, HX = (F_BX - 1) * S + 3;
+    static constexpr int HV = HZ * HY * HX;                       // halo voxels
+    static constexpr int PS = (HV + 47) / 64 * 64 + 16;           // plane stride in floats: >= HV and == 16 (mod 64)
+    static_assert(PS >= HV && PS % 64 == 16, "bank layout");
+    static constexpr size_t lds_bytes(int NT) { return (size_t)(CK * PS + NT * 27 * CK * 16) * sizeof(float); }
+};
+
+struct ConvF32Args {
+    ConvGeom g;
+    SrcDesc s0, s1;          // up to two concatenated sources (skip first, unet.cpp:181)
+    const float* w;          // [27][Cin][CoutP]  (launch_pack_conv_w)
+    const float* bias;
+    float* out;              // channels-last fp32 [voxel][Cout]
+    int CoutP;
+    int tz, ty, tx;          // tile grid
+};
+
+template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) k_conv_f32_mfma(ConvF32Args a) {
+    typedef F32Tile<S, BY, CK> TL;
+    constexpr int F_BY = BY, F_CK = CK, F_HY = TL::HY, F_HX = TL::HX, F_HV = TL::HV, F_PS = TL::PS;
+    extern __shared__ float lds[];
+    float* xs = lds;                          // [F_CK][F_PS]
+    float* wsm = lds + F_CK * F_PS;           // [NT][27][F_CK][16]
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lx = lane & 15, lq = lane >> 4;
+    int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = t % a.tx; t /= a.tx;
+    const int by = t % a.ty, bz = t / a.ty;
+    const int z0 = bz * F_BZ, y0 = by * F_BY, x0 = bx * F_BX;
+    const int co0 = blockIdx.y * (16 * NT);
+
+    f32x4 acc[F_BY][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const float b = a.bias ? a.bias[co0 + n * 16 + lx] : 0.f;
+#pragma unroll
+        for (int r = 0; r < F_BY; ++r) acc[r][n] = f32x4{b, b, b, b};
+    }
+
+    for (int c0 = 0; c0 < g.Cin; c0 += F_CK) {
+        // which source holds channels [c0, c0+8): selects, not an indexed array of descriptors (that would live in scratch)
+        const bool second = c0 >= a.s0.C;
+        const float* sp = (const float*)(second ? a.s1.ptr : a.s0.ptr);
+        const int sC = second ? a.s1.C : a.s0.C, cb = second ? c0 - a.s0.C : c0;
+        const float* sc = second ? a.s1.scale : a.s0.scale;
+        const float* sh = second ? a.s1.shift : a.s0.shift;
+        const int act = second ? a.s1.act : a.s0.act;
+        __syncthreads();   // the previous chunk's MFMAs have read xs / wsm
+        for (int it = tid; it < F_HV * (F_CK / 4); it += 256) {
+            const int hv = it / (F_CK / 4), q = it % (F_CK / 4);
+            const int hz = hv / (F_HY * F_HX), rem = hv - hz * (F_HY * F_HX), hy = rem / F_HX, hx = rem - hy * F_HX;
+            const int iz = z0 * S + hz - 1, iy = y0 * S + hy - 1, ix = x0 * S + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+                const int c = cb + q * 4;
+                v = *(const float4*)(sp + (((int64_t)iz * g.H + iy) * g.W + ix) * sC + c);
+                if (sc) {
+                    const float4 s4 = *(const float4*)(sc + c), h4 = *(const float4*)(sh + c);
+                    v.x = v.x * s4.x + h4.x; v.y = v.y * s4.y + h4.y; v.z = v.z * s4.z + h4.z; v.w = v.w * s4.w + h4.w;
+                }
+                v.x = act_f(v.x, act); v.y = act_f(v.y, act); v.z = act_f(v.z, act); v.w = act_f(v.w, act);
+            }
+            float* d = xs + (q * 4) * F_PS + hv;
+            d[0] = v.x; d[F_PS] = v.y; d[2 * F_PS] = v.z; d[3 * F_PS] = v.w;
+        }
+        for (int it = tid; it < 27 * F_CK * 4 * NT; it += 256) {   // float4 = 4 cout of one (tap, cin)
+            const int c4 = it % (4 * NT), rk = it / (4 * NT), k = rk % F_CK, tap = rk / F_CK;
+            const float4 v = *(const float4*)(a.w + ((int64_t)tap * g.Cin + c0 + k) * a.CoutP + co0 + c4 * 4);
+            const int n = c4 >> 2, cc = (c4 & 3) * 4;
+            *(float4*)(wsm + ((n * 27 + tap) * F_CK + k) * 16 + cc) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kg = 0; kg < F_CK / 4; ++kg) {
+                    float A[F_HY];
+                    const float* xp = xs + (kg * 4 + lq) * F_PS + ((wv * S + kz) * F_HY) * F_HX + lx * S + kx;
+#pragma unroll
+                    for (int i = 0; i < F_HY; ++i) A[i] = xp[i * F_HX];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const float b = wsm[((n * 27 + (kz * 3 + ky) * 3 + kx) * F_CK + kg * 4 + lq) * 16 + lx];
+#pragma unroll
+                            for (int r = 0; r < F_BY; ++r)
+                                acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[r * S + ky], b, acc[r][n], 0, 0, 0);
+                        }
+                }
+    }
+    // C layout of the 16x16 tile: lane (lq, lx) holds rows (= voxels x) 4*lq + j, column (= cout) lx
+    const int z = z0 + wv;
+    if (z < g.Do) {
+#pragma unroll
+        for (int r = 0; r < F_BY; ++r) {
+            const int y = y0 + r;
+            if (y >= g.Ho) continue;
+            float* o = a.out + (((int64_t)z * g.Ho + y) * g.Wo) * g.Cout + co0 + lx;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = x0 + 4 * lq + j;
+                    if (x < g.Wo) o[(int64_t)x * g.Cout + n * 16] = acc[r][n][j];
+                }
+        }
+    }
+}
+
+}  // namespace
+
+bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    if (dtype != 0 || g.ks != 3 || (g.stride != 1 && g.stride != 2) || g.Cout % 16 || g.Cin % 8) return false;
+    return nsrc >= 1 && nsrc <= 2 && src[0].C % 8 == 0 && (nsrc == 1 || src[1].C % 8 == 0);
+}
+
+template <int S, int BY, int CK, int NT> static void launch_f32_variant(ConvF32Args& a, hipStream_t s) {
+    typedef F32Tile<S, BY, CK> TL;
+    const size_t lds = TL::lds_bytes(NT);
+    static bool once = false;   // > 64 KB of dynamic LDS needs the opt-in
+    if (!once) { (void)hipFuncSetAttribute((const void*)k_conv_f32_mfma<S, BY, CK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    a.tz = (a.g.Do + F_BZ - 1) / F_BZ; a.ty = (a.g.Ho + BY - 1) / BY; a.tx = (a.g.Wo + F_BX - 1) / F_BX;
+    k_conv_f32_mfma<S, BY, CK, NT><<<dim3((unsigned)(a.tz * a.ty * a.tx), a.g.Cout / (16 * NT)), 256, lds, s>>>(a);
+}
+
+void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
+                          hipStream_t s) {
+    ConvF32Args a;
+    a.g = g; a.s0 = src[0]; a.s1 = nsrc > 1 ? src[1] : SrcDesc();
+    if (nsrc == 1) a.s0.C = g.Cin;
+    a.w = w_fwd; a.bias = bias; a.out = out; a.CoutP = round_up(g.Cout, 8);
+    // 32 output channels per block halve the input staging; small volumes take 16 so that twice as many blocks share the walk over Cin
+    const int by = g.stride == 1 ? 8 : 4;
+    const int64_t tiles = (int64_t)((g.Do + 3) / 4) * ((g.Ho + by - 1) / by) * ((g.Wo + 15) / 16);
+    const bool wide = g.Cout % 32 == 0 && tiles * (g.Cout / 32) >= 512;
+    if (g.stride == 1) { if (wide) launch_f32_variant<1, 8, 8, 2>(a, s); else launch_f32_variant<1, 8, 8, 1>(a, s); }
+    else               { if (wide) launch_f32_variant<2, 4, 4, 2>(a, s); else launch_f32_variant<2, 4, 4, 1>(a, s); }
+}
+
+}  // namespace unet
