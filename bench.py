@@ -46,14 +46,19 @@ def dominant_kernel(U, size, dtype_name, iters=20):
     sc = torch.empty(nb.value, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
 
-    wp = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-    # exactly what a plan does for decode0.0: filters packed once per step, then ONE launch of the conv kernel per sample
-    # (plain activated input, bias + bf16 store + norm-statistics partials in the epilogue)
-    E.check(E.lib.unet_op_conv3d_pack(edt, w.data_ptr(), wp.data_ptr(), cin, cout, D, H, W, 3, 1, st))
+    if dtype_name == "bf16":
+        wp = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        # exactly what a plan does for decode0.0: filters packed once per step, then ONE launch of the conv kernel per sample
+        # (plain activated input, bias + bf16 store + norm-statistics partials in the epilogue)
+        E.check(E.lib.unet_op_conv3d_pack(edt, w.data_ptr(), wp.data_ptr(), cin, cout, D, H, W, 3, 1, st))
 
-    def run():
-        E.check(E.lib.unet_op_conv3d_fwd_packed(edt, x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), sc.data_ptr(),
-                                                cin, cout, D, H, W, 3, 1, st))
+        def run():
+            E.check(E.lib.unet_op_conv3d_fwd_packed(edt, x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), sc.data_ptr(),
+                                                    cin, cout, D, H, W, 3, 1, st))
+    else:   # fp32 engine: the fp32 matrix-core conv (k_conv_f32_mfma) behind the operator entry point (+ its ~5 us filter repack)
+        def run():
+            E.check(E.lib.unet_op_conv3d_fwd(edt, U.IMPL_AUTO, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), cin, cout, D, H, W,
+                                             3, 1, sc.data_ptr(), st))
     for _ in range(10):
         run()
     torch.cuda.synchronize()
@@ -186,13 +191,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "%s: train step (fwd+loss+bwd+clip+SGD-Nesterov), default UNet3d arch "
                                    "(train.cpp:1054-1069), in=%d out=6, %d^3 volumes, 1 sample per GPU per step%s"
-                                   % ("configs[2]" if (cin, n, a.augment) == (1, 128, False) else "configs[4]-style" if a.augment else
+                                   % ("configs[2]" if (cin, n, a.augment, a.dtype) == (1, 128, False, "bf16") else "configs[4]-style" if a.augment else
                                       "variant", cin, n, ", on-GPU visual_perception_augmentation inside the step" if a.augment else ""),
                        "global_batch": world, "volume": [n, n, n], "parallelism": "dp%d" % world,
                        "flops_per_step_per_sample": step_flops, "params": int(model.flat_params.numel())},
             "step_mfma_frac": (step_flops * world * a.steps / dt) / (peak * world),
             "roofline": {"bound": "mfma", "achieved": kflops / ksec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": kflops / ksec / peak, "traffic": measured_traffic(),
+                         "frac": kflops / ksec / peak, "traffic": measured_traffic() if a.dtype == "bf16" else None,
                          "kernel": "conv3d fwd 32->16 3x3x3 @%d^3 (decode0.0, 23.7%% of forward FLOPs)" % n,
                          "avg_launch_ms": ksec * 1e3},
             "last_loss": loss,
