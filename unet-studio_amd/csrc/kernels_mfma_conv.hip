@@ -22,6 +22,7 @@
 //   single-chunk 32-channel stride-1 layers), k_mfma_conv_small (16^3 and smaller volumes), k_conv_first_mfma (Cin = 1),
 //   k_mfma_pack / k_mfma_pack_batched (fp32 torch layout -> bf16 fragments).
 #include <type_traits>
+#include <cstdlib>
 #include "mfma_util.h"
 
 namespace unet {
@@ -1064,6 +1065,10 @@ template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> stati
         constexpr int T = KD * KD * KD, KSTEPS = CK == 32 ? T : (T + 1) / 2;
         while (nt > 1 && KSTEPS * nt > 32) nt >>= 1;            // keep the chunk's filter fragments LDS-resident
         while (nt > 1 && (int64_t)tiles * (ntt / nt) < 256) nt >>= 1;
+        // a single 16-channel chunk (the dgrad of decode0.0, 16 -> 32 at full resolution): two one-row-tile blocks, each staging the
+        // filter slice once, beat one two-row-tile block (UNET_NT_SINGLE16=0 restores the latter)
+        static const bool single16 = !(getenv("UNET_NT_SINGLE16") && getenv("UNET_NT_SINGLE16")[0] == '0');
+        if (single16 && CK == 16 && a.g.Cin == 16 && nt == 2 && S == 1 && KD == 3) nt = 1;
         if (nt == 4) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
         if (nt == 2) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
         return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, false>(a, s);
