@@ -9,5 +9,6 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import unet_studio_amd as U  # noqa: E402
 
-flops, sec = bench.dominant_kernel(U, 128, "bf16", iters=5)
+dt = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+flops, sec = bench.dominant_kernel(U, 128, dt, iters=5)
 print("dominant kernel: %.3f ms per launch, %.1f TFLOP/s" % (sec * 1e3, flops / sec / 1e12))
