@@ -6,12 +6,13 @@
 //   D[voxel x][cout] += X[voxel x + kx][cin] * W[tap][cin][cout]        M = 16 voxels of one x-row, N = 16 cout, K = 4 cin
 //
 // Block = 256 threads = 4 waves, output tile 4 (z) x BY (y) x 16 (x) voxels x 16*NT output channels; wave w owns the BY rows of
-// z-slice w.  Per CK-channel chunk of the input: the halo tile (stride 1, BY 8: 6 x 10 x 18 voxels; stride 2, BY 4: 9 x 9 x 33) is
+// z-slice w.  Per CK-channel chunk of the input: the halo tile (stride 1, BY 8: 6 x 10 x 18 voxels; stride 2, BY 2: 9 x 5 x 33) is
 // staged channel-major ([cin][voxel], plane stride = 16 mod 64 floats, so the four k-groups of a wave hit four disjoint bank
 // ranges) with the consumer-side transform act(x*scale+shift) applied on the way in (zero padding is applied AFTER it, as the
 // reference pads the activated tensor); the chunk's filter slice is staged as [nt][tap][cin][16].  For one (kz, kx, k-group) a
 // wave reads the halo rows it needs ONCE and feeds them to 3 (ky) x BY (rows) x NT MFMAs (stride 1: 10 + 3*NT LDS reads per
 // 24*NT MFMAs).  Measured at 128^3: 32->16 (58 GFLOP) in 0.60 ms = 97 TFLOP/s of the 157 the fp32 matrix pipe has.
+#include <cstdlib>
 #include "mfma_util.h"
 #include "kernels.h"
 
@@ -156,11 +157,22 @@ void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const
     if (nsrc == 1) a.s0.C = g.Cin;
     a.w = w_fwd; a.bias = bias; a.out = out; a.CoutP = round_up(g.Cout, 8);
     // 32 output channels per block halve the input staging; small volumes take 16 so that twice as many blocks share the walk over Cin
-    const int by = g.stride == 1 ? 8 : 4;
+    const int by = g.stride == 1 ? 8 : 2;
     const int64_t tiles = (int64_t)((g.Do + 3) / 4) * ((g.Ho + by - 1) / by) * ((g.Wo + 15) / 16);
     const bool wide = g.Cout % 32 == 0 && tiles * (g.Cout / 32) >= 512;
+    // levels with few tiles (32^3 and below in the default architecture): a 4x4x16 tile with 16-channel chunks -- twice the blocks,
+    // half the chunk passes (forward at 128^3: 8.4 -> 7.4 ms); the 128^3 layers are faster on the 4x8x16 / 8-channel form
+    // (0.62 vs 0.68 ms for 32->16).  UNET_F32_TILE=0 keeps the large tile everywhere, =1 forces the small one.
+    static const int knob = getenv("UNET_F32_TILE") ? atoi(getenv("UNET_F32_TILE")) : -1;
+    const bool few = tiles * (g.Cout / 16) < 2048;
+    if (g.stride == 1 && !wide && g.Cin % 16 == 0 && src[0].C % 16 == 0 && (knob == 1 || (knob < 0 && few))) {
+        launch_f32_variant<1, 4, 16, 1>(a, s);
+        return;
+    }
     if (g.stride == 1) { if (wide) launch_f32_variant<1, 8, 8, 2>(a, s); else launch_f32_variant<1, 8, 8, 1>(a, s); }
-    else               { if (wide) launch_f32_variant<2, 4, 4, 2>(a, s); else launch_f32_variant<2, 4, 4, 1>(a, s); }
+    // stride 2: 4x2x16 outputs from a 9x5x33 halo in 8-channel chunks (0.37 ms per forward faster than 4x4x16 with 4-channel chunks,
+    // whose halo forced twice the chunk passes)
+    else               { if (wide) launch_f32_variant<2, 2, 8, 2>(a, s); else launch_f32_variant<2, 2, 8, 1>(a, s); }
 }
 
 }  // namespace unet
