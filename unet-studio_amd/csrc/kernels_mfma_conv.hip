@@ -820,6 +820,10 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
     bf16x8 wf[27];
 #pragma unroll
     for (int ks = 0; ks < 27; ++ks) wf[ks] = wp[((size_t)ks * NTT + nt0) * 64 + lane];
+    // Retire these 27 loads here, explicitly.  Otherwise the compiler cannot prove inside the plane loop that they have landed and
+    // guards every use of wf[] with s_waitcnt vmcnt(n), n shrinking to 0 towards the last taps -- which also waits for the input
+    // planes just requested for two steps later, i.e. it serialises the very prefetch the loop is built around.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
     // this lane's patch addresses inside a plane for its two m-tiles (rows 2*wave, 2*wave + 1), per kx (swizzled as in k_mfma_conv_p)
     int mbase[2][3];
 #pragma unroll
@@ -853,9 +857,15 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
     const int cd = cch - (dsel ? a.outC[0] : 0);
     char* obase = (char*)(dsel ? a.out[1] : a.out[0]);
     const int oC = dsel ? a.outC[1] : a.outC[0], oacc = dsel ? a.out_acc[1] : a.out_acc[0];
+    // Outputs leave through a buffer descriptor: a lane outside the volume stores at an offset beyond num_records and the hardware
+    // drops it.  No branch around the store = a fixed number of memory operations per step, which is what lets the compiler wait
+    // with vmcnt(n > 0) for the older input buffer while the younger one is still in flight (launch_conv_z checks the 2 GB bound).
+    const unsigned obytes = obase ? (unsigned)((size_t)a.oD * a.oH * a.oW * oC * 2) : 0u;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)obytes, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
 
     const int nitems = zw.cols_x * zw.cols_y * zw.nseg;
-    bf16x8 R[ITERS];
+    bf16x8 R[ITERS], R2[ITERS];
     const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int seg = item % zw.nseg, col = item / zw.nseg;
@@ -872,22 +882,37 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
             ubase[it] = sptr + (size_t)(ok ? gy * g.W + gx : 0) * vstride;
         }
         const size_t plane_bytes = (size_t)g.H * g.W * vstride;
+        // The plane loads are issued as inline assembly and waited for by hand (wait_planes below).  Left to the compiler, every
+        // use of a prefetched register is guarded by s_waitcnt vmcnt(0..2) -- it cannot count the younger operations across the
+        // loop -- and a step then waits for the loads of the NEXT step's buffer as well, which is the latency this pipeline exists
+        // to hide.  Loads are unconditional (units outside the volume read a valid dummy address and are zeroed when they are
+        // stored to LDS), so every step issues exactly ITERS loads and, once it computes, exactly 2 buffer stores.
         auto prefetch = [&](int pz, bf16x8 (&Rr)[ITERS]) {
             const bool zin = (unsigned)pz < (unsigned)g.D;
             const size_t po = (size_t)(zin ? pz : 0) * plane_bytes;      // uniform
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                Rr[it] = zero8;
-                if (zin && ((umask >> it) & 1u)) Rr[it] = *(const bf16x8*)(ubase[it] + po);
+                const char* ad = ubase[it] + po;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(Rr[it]) : "v"(ad) : "memory");
             }
+        };
+        // vector-memory operations retire in issue order.  Younger than the buffer about to be stored are: the other buffer's ITERS
+        // loads and, once steps compute, the 2 output stores of the previous step (those of the step before may also remain).
+        // No VALU instruction may touch a prefetched register before this wait (the hardware does not interlock VGPR reads against
+        // loads in flight): the registers go straight into ds_write (a memory operation, which the "memory" clobber keeps behind the
+        // wait), out-of-volume units are zeroed by a second ds_write to the same address, and the wait has no register operands
+        // (tied operands made the compiler copy the registers BEFORE the wait on one path).
+        auto wait_planes = [&](bool steady) {
+            if (steady) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         };
         // output pointers of this lane's two voxels, plane zs; advanced by one plane per step
         const int oy[2] = {y0 + 2 * wave, y0 + 2 * wave + 1}, ox = x0 + j;
         const bool ook[2] = {oy[0] < a.oH && ox < a.oW && obase != nullptr, oy[1] < a.oH && ox < a.oW && obase != nullptr};
-        char* optr[2];
+        unsigned ooff[2];     // byte offsets inside the destination tensor (< 2^31)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) optr[i] = obase + ((((size_t)zs * a.oH + (ook[i] ? oy[i] : 0)) * a.oW + (ook[i] ? ox : 0)) * oC + cd) * 2;
-        const size_t oplane = (size_t)a.oH * a.oW * oC * 2;
+        for (int i = 0; i < 2; ++i) ooff[i] = (unsigned)(((((size_t)zs * a.oH + (ook[i] ? oy[i] : 0)) * a.oW + (ook[i] ? ox : 0)) * oC + cd) * 2);
+        const unsigned oplane = (unsigned)((size_t)a.oH * a.oW * oC * 2);
 
         // one output plane; SL = slot of input plane z-1 (compile-time: every LDS address is a per-lane base + an immediate)
         auto plane = [&](auto slc) {
@@ -919,45 +944,60 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                if (ook[i]) {
-                    uint2* p = (uint2*)optr[i];
-                    float v0 = acc[i][0] + b4[0], v1 = acc[i][1] + b4[1], v2 = acc[i][2] + b4[2], v3 = acc[i][3] + b4[3];
-                    if (oacc) {
-                        const uint2 old = *p;
-                        v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
-                    }
-                    uint2 o;
-                    o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
-                    *p = o;
-                    if (a.stats) {
-                        const float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
-                        s1[0] += r0; s1[1] += r1; s1[2] += r2; s1[3] += r3;
-                        s2[0] = fmaf(r0, r0, s2[0]); s2[1] = fmaf(r1, r1, s2[1]); s2[2] = fmaf(r2, r2, s2[2]); s2[3] = fmaf(r3, r3, s2[3]);
-                    }
+                float v0 = acc[i][0] + b4[0], v1 = acc[i][1] + b4[1], v2 = acc[i][2] + b4[2], v3 = acc[i][3] + b4[3];
+                if (oacc && ook[i]) {
+                    const uint2 old = *(const uint2*)(obase + ooff[i]);
+                    v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
                 }
-                optr[i] += oplane;
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                u32x2 o;
+                o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, ook[i] ? (int)ooff[i] : OOB, 0, 0);
+                if (a.stats && ook[i]) {
+                    const float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
+                    s1[0] += r0; s1[1] += r1; s1[2] += r2; s1[3] += r3;
+                    s2[0] = fmaf(r0, r0, s2[0]); s2[1] = fmaf(r1, r1, s2[1]); s2[2] = fmaf(r2, r2, s2[2]); s2[3] = fmaf(r3, r3, s2[3]);
+                }
+                ooff[i] += oplane;
             }
         };
 
-        // (measured: issuing the load of plane pz+2 instead of pz+1 -- two planes of latency ahead, two copies of the step --
-        //  was slower, 0.064 -> 0.076 ms on the 32->16 layer)
-        __syncthreads();                       // previous item's planes are no longer read
-        prefetch(zs - 1, R);
-        for (int pz = zs - 1; pz <= ze; ++pz) {
+        // Input planes are fetched TWO steps ahead: a step takes ~1.7 k cycles of MFMA work per SIMD, a global load under this
+        // kernel's own traffic ~4-5 k, and with 216 VGPRs only two blocks share a CU -- fetched one step ahead, every step waited
+        // for its loads.  Even planes travel through R, odd planes through R2 (the compiler's vmcnt then lets the younger
+        // buffer's loads stay in flight while the older buffer is stored); the step is instantiated once per parity, each with
+        // the two ring slots that parity can meet, so the code is no larger than the one-step-ahead form.
+        // (An earlier two-steps-ahead attempt duplicated all four slot variants in both copies and was slower, 0.064 -> 0.076 ms.)
+        auto step = [&](int pz, bf16x8 (&Rc)[ITERS], auto par) {
+            constexpr int PAR = decltype(par)::value;      // parity of pz
             const int slot = (pz + 1) & 3;
+            const bool zin = (unsigned)pz < (unsigned)g.D;             // Rc holds plane pz
+            wait_planes(pz >= zs + 3);                                 // the previous step stored 2 outputs iff pz - 1 >= zs + 1
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
-                if (ulds[it] >= 0) *(bf16x8*)(smem + slot * PLANE_B + ulds[it]) = R[it];
-            if (pz + 1 <= ze) prefetch(pz + 1, R);
+                if (ulds[it] >= 0) {
+                    char* d = smem + slot * PLANE_B + ulds[it];
+                    const unsigned dl = (unsigned)(size_t)(__attribute__((address_space(3))) char*)d;    // LDS byte address
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(dl), "v"(Rc[it]) : "memory");
+                    if (!(zin && ((umask >> it) & 1u))) *(bf16x8*)d = zero8;   // LDS operations of a wave execute in order
+                }
+            prefetch(pz + 2, Rc);   // always (past the segment's end it reads a valid plane that is never stored): a fixed count of loads per step
             __syncthreads();
-            if (pz < zs + 1) continue;
-            // output plane z = pz-1: its input planes z-1, z, z+1 are resident; slot(z-1) = z & 3
-            switch ((pz - 1) & 3) {
-                case 0: plane(std::integral_constant<int, 0>{}); break;
-                case 1: plane(std::integral_constant<int, 1>{}); break;
-                case 2: plane(std::integral_constant<int, 2>{}); break;
-                default: plane(std::integral_constant<int, 3>{}); break;
-            }
+            if (pz < zs + 1) return;
+            // output plane z = pz-1: its input planes z-1, z, z+1 are resident; slot(z-1) = z & 3 = (pz-1) & 3, of parity 1-PAR
+            if (((pz - 1) & 2) == 0) plane(std::integral_constant<int, 1 - PAR>{});
+            else plane(std::integral_constant<int, 3 - PAR>{});
+        };
+        __syncthreads();                       // previous item's planes are no longer read
+        // the previous item's last two steps prefetched past its end: let those loads land before their registers are reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // always start on an even plane (one idle step when zs - 1 is odd): R's loads are then older than R2's on every path
+        const int pe0 = (zs - 1) & ~1;
+        prefetch(pe0, R);
+        prefetch(pe0 + 1, R2);
+        for (int pe = pe0; pe <= ze; pe += 2) {
+            step(pe, R, std::integral_constant<int, 0>{});
+            if (pe + 1 <= ze) step(pe + 1, R2, std::integral_constant<int, 1>{});
         }
     }
     if (a.stats) {
@@ -985,6 +1025,8 @@ static int launch_conv_z(const MfmaConvArgs& a0, hipStream_t s) {
     const ConvGeom& g = a0.g;
     static const bool off = getenv("UNET_NO_CONV_Z") != nullptr;
     if (off || g.Cin != 32 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
+    for (int k = 0; k < 2; ++k)   // outputs are addressed with 31-bit byte offsets through a buffer descriptor
+        if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return 0;
     ZWork zw;
     zw.cols_x = (g.Wo + 15) / 16; zw.cols_y = (g.Ho + 7) / 8;
     const int cols = zw.cols_x * zw.cols_y, gy = g.Cout / 16;
