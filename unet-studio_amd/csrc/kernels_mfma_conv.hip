@@ -902,8 +902,9 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
         // loads in flight): the registers go straight into ds_write (a memory operation, which the "memory" clobber keeps behind the
         // wait), out-of-volume units are zeroed by a second ds_write to the same address, and the wait has no register operands
         // (tied operands made the compiler copy the registers BEFORE the wait on one path).
-        auto wait_planes = [&](bool steady) {
-            if (steady) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        auto wait_planes = [&](int younger_stores) {   // 0, 2 or 4 output stores are younger than the buffer, plus the other buffer's 3 loads
+            if (younger_stores == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (younger_stores == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         };
         // output pointers of this lane's two voxels, plane zs; advanced by one plane per step
@@ -920,6 +921,7 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
             // A wave's two m-tiles are consecutive rows (2w, 2w+1): tap ky of row 2w+1 reads the same LDS patch as tap ky+1 of row
             // 2w.  Per (kz, kx) group the 4 distinct patch rows are read once and feed 6 MFMAs (2 rows x 3 ky): 36 LDS reads
             // per plane instead of 54, and 96 cycles of MFMA work behind every group of reads.
+            // (two accumulation chains per m-tile -- four independent MFMA chains per wave -- measured no faster: 0.066 ms either way)
             f32x4 acc[2];
             bf16x8 xr[2][4];
             auto load_group = [&](int gi, int sl) {     // gi = kz*3 + kx
@@ -968,11 +970,19 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
         // buffer's loads stay in flight while the older buffer is stored); the step is instantiated once per parity, each with
         // the two ring slots that parity can meet, so the code is no larger than the one-step-ahead form.
         // (An earlier two-steps-ahead attempt duplicated all four slot variants in both copies and was slower, 0.064 -> 0.076 ms.)
+        // A step first computes output plane z = pz-2 -- its input planes pz-3..pz-1 were stored in earlier steps -- and only then
+        // waits for plane pz, stores it and requests plane pz+2: the stores and their barrier have no consumer inside the step,
+        // and a load has two steps plus one plane of MFMA work to arrive.
         auto step = [&](int pz, bf16x8 (&Rc)[ITERS], auto par) {
-            constexpr int PAR = decltype(par)::value;      // parity of pz
+            constexpr int PAR = decltype(par)::value;      // parity of pz = parity of z
+            const bool computes = pz >= zs + 2;
+            if (computes) {   // slot(z-1) = z & 3, of parity PAR
+                if (((pz - 2) & 2) == 0) plane(std::integral_constant<int, PAR>{});
+                else plane(std::integral_constant<int, 2 + PAR>{});
+            }
             const int slot = (pz + 1) & 3;
             const bool zin = (unsigned)pz < (unsigned)g.D;             // Rc holds plane pz
-            wait_planes(pz >= zs + 3);                                 // the previous step stored 2 outputs iff pz - 1 >= zs + 1
+            wait_planes(pz >= zs + 3 ? 4 : (computes ? 2 : 0));       // stores of this step and of the previous one, if they computed
 #pragma unroll
             for (int it = 0; it < ITERS; ++it)
                 if (ulds[it] >= 0) {
@@ -981,12 +991,8 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
                     asm volatile("ds_write_b128 %0, %1" :: "v"(dl), "v"(Rc[it]) : "memory");
                     if (!(zin && ((umask >> it) & 1u))) *(bf16x8*)d = zero8;   // LDS operations of a wave execute in order
                 }
-            prefetch(pz + 2, Rc);   // always (past the segment's end it reads a valid plane that is never stored): a fixed count of loads per step
+            prefetch(pz + 2, Rc);   // always (past the segment's end it reads a valid plane that is never used): a fixed count of loads per step
             __syncthreads();
-            if (pz < zs + 1) return;
-            // output plane z = pz-1: its input planes z-1, z, z+1 are resident; slot(z-1) = z & 3 = (pz-1) & 3, of parity 1-PAR
-            if (((pz - 1) & 2) == 0) plane(std::integral_constant<int, 1 - PAR>{});
-            else plane(std::integral_constant<int, 3 - PAR>{});
         };
         __syncthreads();                       // previous item's planes are no longer read
         // the previous item's last two steps prefetched past its end: let those loads land before their registers are reused
@@ -995,9 +1001,9 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
         const int pe0 = (zs - 1) & ~1;
         prefetch(pe0, R);
         prefetch(pe0 + 1, R2);
-        for (int pe = pe0; pe <= ze; pe += 2) {
+        for (int pe = pe0; pe <= ze + 1; pe += 2) {     // the last output plane ze-1 is computed at pz = ze+1
             step(pe, R, std::integral_constant<int, 0>{});
-            if (pe + 1 <= ze) step(pe + 1, R2, std::integral_constant<int, 1>{});
+            if (pe + 1 <= ze + 1) step(pe + 1, R2, std::integral_constant<int, 1>{});
         }
     }
     if (a.stats) {
