@@ -83,7 +83,7 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline(size, budget_steps=1):
+def cpu_baseline(size, budget_steps=3):   # ~3 s per 128^3 step on 16 cores: 1 warm-up + 3 timed steps = ~12 s of CPU work
     """ATen-CPU train micro-step (forward + losses + backward + step epilogue), fp32, all host cores."""
     from oracle import aten_ref as A
     try:
