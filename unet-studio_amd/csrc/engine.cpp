@@ -492,6 +492,8 @@ struct Exec {
                         else
                             launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        else if (!dry && any && p.impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(p.dtype, cg, dg, op.nsrc))
+                            launch_conv_f32_mfma_dgrad(cg, (const float*)gptr(t), wd, dg, op.nsrc, s);
                         else if (!dry && (any)) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
                         if (p.wgrad_mfma[i]) {
@@ -962,7 +964,8 @@ int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w,
             launch_mfma_conv_dgrad(g, dy, wm, &d, 1, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
-            launch_conv_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
+            if (impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(dtype, g, &d, 1)) launch_conv_f32_mfma_dgrad(g, (const float*)dy, wd, &d, 1, s);
+            else launch_conv_dgrad_direct(dtype, g, dy, wd, &d, 1, s);
         }
     })
 }

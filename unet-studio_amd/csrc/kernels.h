@@ -189,6 +189,8 @@ void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mf
 bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
                           hipStream_t s);
+bool conv_f32_mfma_dgrad_supported(int dtype, const ConvGeom& g, const DstGrad* dst, int ndst);
+void launch_conv_f32_mfma_dgrad(const ConvGeom& g, const float* dy, const float* w_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
 
 // kernels_augment.hip: on-GPU sample augmentation (include/unet_augment.h)
 size_t augment_scratch_bytes(const UnetAugmentRecipe& r);

@@ -34,7 +34,12 @@ struct ConvF32Args {
     SrcDesc s0, s1;          // up to two concatenated sources (skip first, unet.cpp:181)
     const float* w;          // [27][Cin][CoutP]  (launch_pack_conv_w)
     const float* bias;
-    float* out;              // channels-last fp32 [voxel][Cout]
+    float* out;              // channels-last fp32 [voxel][Cout]   (forward)
+    // dgrad: the kernel runs on dy with the tap order reversed and the [tap][cout][cinP] filter copy; its "output channels" are the
+    // layer's input channels, which go to up to two gradient tensors (the two concatenated sources), written or accumulated
+    int flip;                // 1: filter tap = 26 - tap
+    float* dst[2];
+    int dstC[2], dst_acc[2];
     int CoutP;
     int tz, ty, tx;          // tile grid
 };
@@ -89,7 +94,7 @@ template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) 
         }
         for (int it = tid; it < 27 * F_CK * 4 * NT; it += 256) {   // float4 = 4 cout of one (tap, cin)
             const int c4 = it % (4 * NT), rk = it / (4 * NT), k = rk % F_CK, tap = rk / F_CK;
-            const float4 v = *(const float4*)(a.w + ((int64_t)tap * g.Cin + c0 + k) * a.CoutP + co0 + c4 * 4);
+            const float4 v = *(const float4*)(a.w + ((int64_t)(a.flip ? 26 - tap : tap) * g.Cin + c0 + k) * a.CoutP + co0 + c4 * 4);
             const int n = c4 >> 2, cc = (c4 & 3) * 4;
             *(float4*)(wsm + ((n * 27 + tap) * F_CK + k) * 16 + cc) = v;
         }
@@ -117,18 +122,31 @@ template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) 
     }
     // C layout of the 16x16 tile: lane (lq, lx) holds rows (= voxels x) 4*lq + j, column (= cout) lx
     const int z = z0 + wv;
-    if (z < g.Do) {
+    // destination of this block's channel tile (a tile never straddles two gradient tensors: launch_conv_f32_mfma_dgrad picks NT)
+    float* ob = a.out;
+    int oC = g.Cout, ocb = co0, oacc = 0;
+    if (a.flip) {
+        const int second = co0 >= a.dstC[0] ? 1 : 0;
+        ob = second ? a.dst[1] : a.dst[0];
+        oC = second ? a.dstC[1] : a.dstC[0];
+        ocb = co0 - (second ? a.dstC[0] : 0);
+        oacc = second ? a.dst_acc[1] : a.dst_acc[0];
+    }
+    if (z < g.Do && ob) {
 #pragma unroll
         for (int r = 0; r < F_BY; ++r) {
             const int y = y0 + r;
             if (y >= g.Ho) continue;
-            float* o = a.out + (((int64_t)z * g.Ho + y) * g.Wo) * g.Cout + co0 + lx;
+            float* o = ob + (((int64_t)z * g.Ho + y) * g.Wo) * oC + ocb + lx;
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int x = x0 + 4 * lq + j;
-                    if (x < g.Wo) o[(int64_t)x * g.Cout + n * 16] = acc[r][n][j];
+                    if (x < g.Wo) {
+                        float* q = o + (int64_t)x * oC + n * 16;
+                        *q = oacc ? *q + acc[r][n][j] : acc[r][n][j];
+                    }
                 }
         }
     }
@@ -156,6 +174,7 @@ void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const
     a.g = g; a.s0 = src[0]; a.s1 = nsrc > 1 ? src[1] : SrcDesc();
     if (nsrc == 1) a.s0.C = g.Cin;
     a.w = w_fwd; a.bias = bias; a.out = out; a.CoutP = round_up(g.Cout, 8);
+    a.flip = 0; a.dst[0] = a.dst[1] = nullptr; a.dstC[0] = a.dstC[1] = 0; a.dst_acc[0] = a.dst_acc[1] = 0;
     // 32 output channels per block halve the input staging; small volumes take 16 so that twice as many blocks share the walk over Cin
     const int by = g.stride == 1 ? 8 : 2;
     const int64_t tiles = (int64_t)((g.Do + 3) / 4) * ((g.Ho + by - 1) / by) * ((g.Wo + 15) / 16);
@@ -173,6 +192,37 @@ void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const
     // stride 2: 4x2x16 outputs from a 9x5x33 halo in 8-channel chunks (0.37 ms per forward faster than 4x4x16 with 4-channel chunks,
     // whose halo forced twice the chunk passes)
     else               { if (wide) launch_f32_variant<2, 2, 8, 2>(a, s); else launch_f32_variant<2, 2, 8, 1>(a, s); }
+}
+
+// ---- input gradient of a stride-1 3x3x3 conv: dx[u][ci] = sum_k sum_co dy[u + 1 - k][co] * w[co][ci][k] ----
+bool conv_f32_mfma_dgrad_supported(int dtype, const ConvGeom& g, const DstGrad* dst, int ndst) {
+    if (dtype != 0 || g.ks != 3 || g.stride != 1 || g.Cout % 8 || g.Cin % 16 || ndst < 1 || ndst > 2) return false;
+    int c = 0;
+    for (int k = 0; k < ndst; ++k) { if (dst[k].C % 16) return false; c += dst[k].C; }
+    return c == g.Cin;
+}
+
+void launch_conv_f32_mfma_dgrad(const ConvGeom& g, const float* dy, const float* w_dgrad, const DstGrad* dst, int ndst, hipStream_t s) {
+    ConvF32Args a;
+    a.g = g;                      // the kernel's view: input = dy (Cout channels), output = dx (Cin channels), same volume
+    a.g.Cin = g.Cout; a.g.Cout = g.Cin; a.g.D = g.Do; a.g.H = g.Ho; a.g.W = g.Wo;
+    a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
+    a.s0 = SrcDesc(); a.s0.ptr = dy; a.s0.C = g.Cout; a.s1 = SrcDesc();
+    a.w = w_dgrad; a.bias = nullptr; a.out = nullptr; a.CoutP = round_up(g.Cin, 8);
+    a.flip = 1;
+    for (int k = 0; k < 2; ++k) {
+        a.dst[k] = k < ndst ? (float*)dst[k].ptr : nullptr;
+        a.dstC[k] = k < ndst ? dst[k].C : 0;
+        a.dst_acc[k] = k < ndst ? dst[k].accumulate : 0;
+    }
+    // 32-channel tiles only when no tile can straddle the two gradient tensors
+    const bool nt2_ok = g.Cin % 32 == 0 && (ndst == 1 || dst[0].C % 32 == 0);
+    const int64_t tiles = (int64_t)((g.D + 3) / 4) * ((g.H + 7) / 8) * ((g.W + 15) / 16);
+    const bool wide = nt2_ok && tiles * (g.Cin / 32) >= 512;
+    const bool few = tiles * (g.Cin / 16) < 2048;
+    if (wide) launch_f32_variant<1, 8, 8, 2>(a, s);
+    else if (few && g.Cout % 16 == 0) launch_f32_variant<1, 4, 16, 1>(a, s);
+    else launch_f32_variant<1, 8, 8, 1>(a, s);
 }
 
 }  // namespace unet
