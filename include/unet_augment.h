@@ -87,6 +87,29 @@ int unet_augment_scratch_bytes(const UnetAugmentRecipe* recipe, size_t* bytes);
 int unet_augment_run(const UnetAugmentRecipe* recipe, float* image, float* label, void* scratch, size_t scratch_bytes,
                      void* stream);
 
+/* ---- simulate_modality (train.cpp:43-117 with labels, :119-178 without; called per template sample at train.cpp:460-462) ----
+ * A random polynomial contrast: tissue = per-label random level (or the image itself), smoothed twice; every voxel above 0.02
+ * becomes pow(sum of 20 random monomials in (x, tissue, 1-x, 1-tissue), gamma); the result is stretched to [0,1] over the
+ * labelled voxels (all voxels without labels).  As with the augmentation, the caller makes the draws (tipl::uniform_dist) in the
+ * reference's order and passes them; the engine is a deterministic function of (recipe, t1w, label), in place on t1w. */
+#define UNET_SIM_TERMS 20
+#define UNET_SIM_MAX_LABELS 256
+
+typedef struct {
+    int dims[3];
+    int with_label;                              /* 1: train.cpp:43 overload (label volume given), 0: train.cpp:119 overload */
+    int max_label;                               /* label values are 0..max_label (< UNET_SIM_MAX_LABELS) */
+    float lut[UNET_SIM_MAX_LABELS];              /* 0.4 + rand*0.2 per label value, train.cpp:56-58 */
+    unsigned char term_a[UNET_SIM_TERMS], term_b[UNET_SIM_TERMS], term_c[UNET_SIM_TERMS], term_d[UNET_SIM_TERMS];   /* exponents 0..3 */
+    float term_w[UNET_SIM_TERMS];                /* train.cpp:65-78 */
+    float gamma;                                 /* 0.6 + 1.2*rand, train.cpp:80 */
+} UnetSimulateRecipe;
+
+int unet_simulate_modality_scratch_bytes(const UnetSimulateRecipe* recipe, size_t* bytes);
+/* t1w: D*H*W fp32 in [0,1], rewritten in place; label: D*H*W fp32 label values (ignored when with_label == 0, may be NULL). */
+int unet_simulate_modality_run(const UnetSimulateRecipe* recipe, float* t1w, const float* label, void* scratch, size_t scratch_bytes,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,3 +252,45 @@ def augment(r, image, label):
         v = np.fmax(v, F(0))
         res.append(_norm(v, v.max()))
     return np.stack(res).astype(F), out_label
+
+
+def _smooth(v):
+    """The smoothing shared with the HIP kernel (k_sim_smooth): 3x3x3 binomial (1,2,1)^3/64, border voxels replicated, taps
+    accumulated in (kz, ky, kx) order.  Stands in for tipl::filter::gaussian (TIPL, absent: parity unpinned)."""
+    D, H, W = v.shape
+    p = np.pad(v, 1, mode="edge")
+    acc = np.zeros_like(v)
+    for kz in range(3):
+        for ky in range(3):
+            for kx in range(3):
+                w = F((2 if kz == 1 else 1) * (2 if ky == 1 else 1) * (2 if kx == 1 else 1)) * F(1.0 / 64.0)
+                acc = acc + w * p[kz:kz + D, ky:ky + H, kx:kx + W]
+    return acc.astype(F)
+
+
+def simulate_modality(r, t1w, label=None):
+    """train.cpp:43-117 (with labels) / :119-178 (without), as a function of the recipe of unet-studio_amd/augment.py."""
+    t1w = np.array(t1w, F)
+    if r["with_label"]:
+        lut = np.array(r["lut"], F)
+        tissue = lut[np.clip(label.astype(np.int64), 0, r["max_label"])]          # :59-60
+    else:
+        tissue = t1w.copy()                                                        # :126
+    tissue = _smooth(_smooth(tissue))                                              # :62-63
+    x, z = t1w, tissue
+    rx, rz = F(1) - x, F(1) - z
+    one = np.ones_like(x)
+    px, pz = [one, x, x * x, x * x * x], [one, z, z * z, z * z * z]
+    qx, qz = [one, rx, rx * rx, rx * rx * rx], [one, rz, rz * rz, rz * rz * rz]
+    s = np.zeros_like(x)
+    for a, b, c, d, w in r["terms"]:
+        s = s + F(w) * px[a] * pz[b] * qx[c] * qz[d]
+    keep = ~(x <= F(0.02))
+    with np.errstate(invalid="ignore"):
+        out = np.where(keep, np.power(s, F(r["gamma"])), F(0)).astype(F)          # :84-104
+    sel = keep & ((label != 0) if r["with_label"] else True)
+    if sel.any():
+        mn, mx = out[sel].min(), out[sel].max()
+        if mx > mn:                                                                # :110-115
+            out = np.clip((out - mn) * (F(1) / (mx - mn)), F(0), F(1)).astype(F)
+    return out

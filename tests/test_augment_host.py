@@ -155,3 +155,54 @@ def test_oracle_perlin_is_a_lattice_noise():
     x = np.linspace(0, 4, 401, dtype=np.float32)
     v = R._perlin_at(p, x, x * np.float32(0.7), x * np.float32(1.3))
     assert np.abs(v).max() <= 1.5 and np.abs(np.diff(v)).max() < 0.05
+
+
+# ---- simulate_modality (train.cpp:43-178) ----
+def test_simulate_recipe_layout_and_draws(tmp_path):
+    fields = [f[0] for f in G.SimRecipe._fields_]
+    src = tmp_path / "layout_sim.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "unet_augment.h"\nint main(void){\n'
+                   'printf("%zu\\n", sizeof(UnetSimulateRecipe));\n' +
+                   "".join('printf("%%zu\\n", offsetof(UnetSimulateRecipe, %s));\n' % f for f in fields) + "return 0;}\n")
+    exe = tmp_path / "layout_sim"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == C.sizeof(G.SimRecipe) and out[1:] == [getattr(G.SimRecipe, f).offset for f in fields]
+    # draw order (train.cpp:52-80): lut from the float generator first, then per term (a,b) until a+b != 0, c, d from the integer
+    # generator and w from the float one, then gamma
+    ints = iter([0, 0, 0, 0, 3, 1, 2, 0] + [1, 2, 3, 0] * 19)
+    floats = iter([0.0, 0.5, 1.0] + [0.25] * 20 + [0.5])
+    r = G.make_simulate_recipe((8, 8, 8), 2, 0, rand_int=lambda n: next(ints), rand_float=lambda: np.float32(next(floats)))
+    assert [float(v) for v in r["lut"]] == [np.float32(0.4), np.float32(0.5), np.float32(0.4) + np.float32(0.2)]
+    assert r["terms"][0][:4] == (3, 1, 2, 0) and r["terms"][1][:4] == (1, 2, 3, 0) and len(r["terms"]) == 20
+    assert r["gamma"] == np.float32(0.6) + np.float32(1.2) * np.float32(0.5)
+    assert G.make_simulate_recipe((8, 8, 8), None, 0)["with_label"] == 0
+    n = C.c_size_t()
+    s = G.sim_to_struct(r)
+    assert U.engine.lib.unet_simulate_modality_scratch_bytes(C.byref(s), C.byref(n)) == 0 and n.value > 2 * 4 * 512
+    s.term_a[0] = 4
+    assert U.engine.lib.unet_simulate_modality_scratch_bytes(C.byref(s), C.byref(n)) != 0
+    with pytest.raises(ValueError):
+        G.make_simulate_recipe((8, 8, 8), 256, 0)
+
+
+def test_oracle_simulate_modality_known_answers():
+    # one monomial x^1 with weight 1, gamma 1, no labels: out = stretch(x) over the voxels above the 0.02 cut
+    r = {"dims": [4, 4, 4], "with_label": 0, "max_label": 0, "lut": [], "gamma": np.float32(1.0),
+         "terms": [(1, 0, 0, 0, np.float32(1.0))] + [(1, 0, 0, 0, np.float32(0.0))] * 19}
+    x = np.linspace(0.0, 1.0, 64, dtype=np.float32).reshape(4, 4, 4)
+    o = R.simulate_modality(r, x)
+    keep = x > 0.02
+    mn, mx = x[keep].min(), x[keep].max()
+    assert np.allclose(o[keep], (x[keep] - mn) / (mx - mn), atol=1e-6) and np.all(o[~keep] == 0)
+    # the smoothing: a constant stays constant, an impulse spreads as (1,2,1)^3/64 with replicated borders
+    assert np.array_equal(R._smooth(np.full((3, 4, 5), 2.0, np.float32)), np.full((3, 4, 5), 2.0, np.float32))
+    imp = np.zeros((5, 5, 5), np.float32); imp[2, 2, 2] = 64
+    sm = R._smooth(imp)
+    assert sm[2, 2, 2] == 8 and sm[2, 2, 1] == 4 and sm[1, 1, 2] == 2 and sm[1, 1, 1] == 1 and sm.sum() == 64
+    # with labels: the stretch uses labelled voxels only, the look-up table sets the tissue level
+    r2 = dict(r, with_label=1, max_label=1, lut=[np.float32(0.4), np.float32(0.6)])
+    lab = np.zeros((4, 4, 4), np.float32); lab[2:] = 1
+    o2 = R.simulate_modality(r2, x, lab)
+    sel = keep & (lab != 0)
+    assert o2[sel].min() == 0.0 and o2[sel].max() == 1.0 and np.all(o2[keep & (lab == 0)] == 0.0)   # below the labelled minimum: clamped

@@ -174,3 +174,41 @@ def test_augmented_source_feeds_a_train_step():
     s = tr.step()
     torch.cuda.synchronize()
     assert torch.isfinite(s).all()
+
+
+# ---- simulate_modality (train.cpp:43-178) ----
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("with_label", [True, False])
+@pytest.mark.parametrize("shape", [(24, 20, 16), (33, 17, 21), (8, 8, 8)])
+def test_simulate_modality_matches_the_restatement(shape, with_label, seed):
+    img, lab = _sample(shape, 1, 5, seed)
+    t1w = np.clip(img[0], 0, 1).astype(np.float32)
+    t1w[lab == 0] *= 0.02          # a background at / below the 0.02 cut (train.cpp:86-90)
+    r = G.make_simulate_recipe(shape, 4 if with_label else None, seed)
+    x = torch.from_numpy(t1w.copy()).to(DEV)
+    l = torch.from_numpy(lab.copy()).to(DEV)
+    G.simulate(r, x, l if with_label else None)
+    torch.cuda.synchronize()
+    got, ref = x.cpu().numpy(), R.simulate_modality(r, t1w, lab)
+    assert np.isfinite(got).all() and got.min() >= 0.0 and got.max() <= 1.0
+    assert (ref > 0).mean() > 0.1, "degenerate case"
+    assert np.abs(got - ref).max() < 2e-5     # powf / the min-max stretch amplify last-bit differences of the 20-term sum
+    assert np.all(got[t1w <= 0.02] == 0.0)    # the cut voxels stay 0 through the stretch (clamped)
+
+
+def test_simulate_modality_at_full_size_and_errors():
+    n = 256
+    g = torch.Generator(device=DEV)
+    g.manual_seed(1)
+    x = torch.rand((n, n, n), device=DEV, generator=g)
+    lab = (torch.rand((n, n, n), device=DEV, generator=g) * 6).floor()
+    r = G.make_simulate_recipe((n, n, n), 5, 7)
+    a, b = x.clone(), x.clone()
+    G.simulate(r, a, lab)
+    G.simulate(r, b, lab)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float(a.min()) == 0.0 and float(a.max()) == 1.0     # deterministic, stretched over labelled voxels
+    with pytest.raises(U.UNetError):
+        G.simulate(r, x.clone(), None)
+    with pytest.raises(U.UNetError):
+        G.simulate(r, x.cpu(), lab.cpu())

@@ -286,3 +286,83 @@ class AugmentedVolumes:
         r = make_recipe(self.options, (W, H, D), x.shape[1], self.is_label, self.base_seed + index, label_depth=D)
         self._scratch = augment(r, x.view(-1), lab.view(-1), self._scratch)
         return x, lab.to(torch.int64)[None]
+
+
+# ---- simulate_modality (train.cpp:43-178) --------------------------------------------------------------------------------
+SIM_TERMS, SIM_MAX_LABELS = 20, 256
+
+
+class SimRecipe(C.Structure):
+    """UnetSimulateRecipe, field for field."""
+    _fields_ = [
+        ("dims", C.c_int * 3), ("with_label", C.c_int), ("max_label", C.c_int), ("lut", C.c_float * SIM_MAX_LABELS),
+        ("term_a", C.c_ubyte * SIM_TERMS), ("term_b", C.c_ubyte * SIM_TERMS), ("term_c", C.c_ubyte * SIM_TERMS),
+        ("term_d", C.c_ubyte * SIM_TERMS), ("term_w", C.c_float * SIM_TERMS), ("gamma", C.c_float),
+    ]
+
+
+engine._sig("unet_simulate_modality_scratch_bytes", C.c_int, C.POINTER(SimRecipe), C.POINTER(C.c_size_t))
+engine._sig("unet_simulate_modality_run", C.c_int, C.POINTER(SimRecipe), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+EXPORTS += ["unet_simulate_modality_scratch_bytes", "unet_simulate_modality_run"]
+
+
+def make_simulate_recipe(image_shape, max_label, seed, rand_int=None, rand_float=None):
+    """The draws of simulate_modality in the reference's order (train.cpp:52-80): two generators, tipl::uniform_dist<int>(seed)
+    and tipl::uniform_dist<float>(0,1,seed+1) -- stand-ins here (numpy MT19937), parity unpinned as for the augmentation.
+    max_label = None selects the overload without a label volume (train.cpp:119)."""
+    if rand_int is None:
+        ri = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+        rand_int = lambda n: int(ri.randint(0, n))
+    if rand_float is None:
+        rf = np.random.RandomState((int(seed) + 1) & 0xFFFFFFFF)
+        rand_float = lambda: F(rf.uniform(0.0, 1.0))
+    r = {"dims": [int(v) for v in image_shape], "with_label": int(max_label is not None), "max_label": int(max_label or 0)}
+    if max_label is not None and not 0 <= max_label < SIM_MAX_LABELS:
+        raise ValueError("max_label must be in 0..%d" % (SIM_MAX_LABELS - 1))
+    r["lut"] = [F(F(0.4) + rand_float() * F(0.2)) for _ in range(r["max_label"] + 1)] if max_label is not None else []   # :56-58
+    r["terms"] = []
+    for _ in range(SIM_TERMS):                       # :65-78
+        while True:
+            a, b = rand_int(4), rand_int(4)
+            if a + b != 0:
+                break
+        c, d = rand_int(4), rand_int(4)
+        r["terms"].append((a, b, c, d, rand_float()))
+    r["gamma"] = F(F(0.6) + F(1.2) * rand_float())   # :80
+    return r
+
+
+def sim_to_struct(r):
+    s = SimRecipe()
+    s.dims[:] = r["dims"]
+    s.with_label, s.max_label, s.gamma = r["with_label"], r["max_label"], float(r["gamma"])
+    for k, v in enumerate(r["lut"]):
+        s.lut[k] = float(v)
+    for k, (a, b, c, d, w) in enumerate(r["terms"]):
+        s.term_a[k], s.term_b[k], s.term_c[k], s.term_d[k], s.term_w[k] = a, b, c, d, float(w)
+    return s
+
+
+def simulate(recipe, t1w, label=None, scratch=None):
+    """Runs one recipe in place on device tensors: t1w fp32 (D,H,W) in [0,1]; label fp32 (D,H,W) when the recipe has labels."""
+    import torch
+    s = recipe if isinstance(recipe, SimRecipe) else sim_to_struct(recipe)
+    n = s.dims[0] * s.dims[1] * s.dims[2]
+    if not t1w.is_cuda or t1w.dtype != torch.float32 or not t1w.is_contiguous() or t1w.numel() != n:
+        raise engine.UNetError("simulate: t1w must be a contiguous float32 device tensor of the recipe's size (there is no CPU path)")
+    if s.with_label and (label is None or not label.is_cuda or label.dtype != torch.float32 or not label.is_contiguous() or label.numel() != n):
+        raise engine.UNetError("simulate: the recipe needs a float32 device label volume of the same size")
+    need = C.c_size_t()
+    engine.check(engine.lib.unet_simulate_modality_scratch_bytes(C.byref(s), C.byref(need)))
+    if scratch is None or scratch.numel() * scratch.element_size() < need.value:
+        scratch = torch.empty(need.value, dtype=torch.uint8, device=t1w.device)
+    st = torch.cuda.current_stream(t1w.device).cuda_stream
+    engine.check(engine.lib.unet_simulate_modality_run(C.byref(s), t1w.data_ptr(), label.data_ptr() if s.with_label else None,
+                                                       scratch.data_ptr(), scratch.numel() * scratch.element_size(), st))
+    return scratch
+
+
+def simulate_modality(t1w, label=None, max_label=None, seed=0):
+    """The reference entry points (train.cpp:43-46 / :119): in place on a device volume already normalised to [0,1]."""
+    D, H, W = t1w.shape[-3:]
+    simulate(make_simulate_recipe((W, H, D), max_label if label is not None else None, seed), t1w, label)

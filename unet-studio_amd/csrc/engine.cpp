@@ -1074,4 +1074,33 @@ int unet_augment_run(const UnetAugmentRecipe* recipe, float* image, float* label
     })
 }
 
+// ---- simulate_modality (include/unet_augment.h) ----
+static const char* simulate_recipe_error(const UnetSimulateRecipe* r) {
+    if (!r) return "unet_simulate_modality: null recipe";
+    for (int d = 0; d < 3; ++d)
+        if (r->dims[d] < 1) return "unet_simulate_modality: dims must be positive";
+    if (r->with_label && (r->max_label < 0 || r->max_label >= UNET_SIM_MAX_LABELS)) return "unet_simulate_modality: max_label out of range";
+    for (int k = 0; k < UNET_SIM_TERMS; ++k)
+        if (r->term_a[k] > 3 || r->term_b[k] > 3 || r->term_c[k] > 3 || r->term_d[k] > 3) return "unet_simulate_modality: exponents must be 0..3";
+    return nullptr;
+}
+int unet_simulate_modality_scratch_bytes(const UnetSimulateRecipe* recipe, size_t* bytes) {
+    if (const char* e = simulate_recipe_error(recipe)) return fail(e);
+    if (!bytes) return fail("unet_simulate_modality_scratch_bytes: null output");
+    *bytes = simulate_scratch_bytes(*recipe);
+    return 0;
+}
+int unet_simulate_modality_run(const UnetSimulateRecipe* recipe, float* t1w, const float* label, void* scratch, size_t scratch_bytes,
+                               void* stream) {
+    if (const char* e = simulate_recipe_error(recipe)) return fail(e);
+    if (!t1w || !scratch || (recipe->with_label && !label)) return fail("unet_simulate_modality_run: null device pointer");
+    if (scratch_bytes < simulate_scratch_bytes(*recipe)) return fail("unet_simulate_modality_run: scratch too small");
+    OP_TRY({
+        hipPointerAttribute_t at;
+        HIP_OK(hipPointerGetAttributes(&at, t1w));
+        DeviceGuard guard(at.device);
+        launch_simulate_modality(*recipe, t1w, label, scratch, (hipStream_t)stream);
+    })
+}
+
 }  // extern "C"

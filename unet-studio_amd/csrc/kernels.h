@@ -195,5 +195,7 @@ void launch_conv_f32_mfma_dgrad(const ConvGeom& g, const float* dy, const float*
 // kernels_augment.hip: on-GPU sample augmentation (include/unet_augment.h)
 size_t augment_scratch_bytes(const UnetAugmentRecipe& r);
 void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void* scratch, hipStream_t st);
+size_t simulate_scratch_bytes(const UnetSimulateRecipe& r);
+void launch_simulate_modality(const UnetSimulateRecipe& r, float* t1w, const float* label, void* scratch, hipStream_t st);
 
 }  // namespace unet

@@ -590,4 +590,152 @@ void launch_augment(const UnetAugmentRecipe& r, float* image, float* label, void
     k_aug_final<<<nb, AUG_T, 0, st>>>(g, mode, out, out_label, image, label, cells);
 }
 
+// ================================================================================================================
+// simulate_modality (include/unet_augment.h; train.cpp:43-178): three passes over a resident volume
+//   k_sim_smooth x2   tipl::filter::gaussian twice (train.cpp:62-63): here the 3x3x3 binomial (1,2,1)^3/64 with the border voxels
+//                     replicated -- TIPL's kernel is not in the reference tree (parity unpinned); the first pass reads the tissue
+//                     volume through the label look-up table (train.cpp:59-60) instead of materialising it
+//   k_sim_remap       the 20-term polynomial + pow (train.cpp:84-104), per-block min / max over the qualifying voxels
+//   k_sim_final       the stretch to [0,1] and clamp (train.cpp:110-115)
+// ================================================================================================================
+namespace {
+
+struct SimTables {
+    float lut[UNET_SIM_MAX_LABELS];
+    float term_w[UNET_SIM_TERMS];
+    unsigned char ta[UNET_SIM_TERMS], tb[UNET_SIM_TERMS], tc[UNET_SIM_TERMS], td[UNET_SIM_TERMS];
+    float gamma;
+    int with_label, max_label;
+};
+
+__global__ void k_sim_upload(SimTables t, SimTables* dst) {
+    const unsigned* s = (const unsigned*)&t;
+    unsigned* d = (unsigned*)dst;
+    for (unsigned i = threadIdx.x; i < sizeof(SimTables) / 4; i += blockDim.x) d[i] = s[i];
+}
+static_assert(sizeof(SimTables) % 4 == 0, "word copy");
+
+// dst = binomial 3x3x3 of src'; src' = lut[label] (FIRST && with_label), else src
+template <bool FIRST>
+__global__ void __launch_bounds__(AUG_T) k_sim_smooth(int W, int H, int D, const SimTables* __restrict__ T, const float* __restrict__ src,
+                                                       float* __restrict__ dst) {
+    int x, y, z;
+    if (!row_voxel(W, H, x, y, z)) return;
+    const bool lut = FIRST && T->with_label;
+    float acc = 0.f;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+        const int zz = min(max(z + kz - 1, 0), D - 1);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = min(max(y + ky - 1, 0), H - 1);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = min(max(x + kx - 1, 0), W - 1);
+                float v = src[((int64_t)zz * H + yy) * W + xx];
+                if (lut) v = T->lut[min(max((int)v, 0), T->max_label)];
+                const float w = (float)((kz == 1 ? 2 : 1) * (ky == 1 ? 2 : 1) * (kx == 1 ? 2 : 1)) * (1.0f / 64.0f);
+                acc += w * v;
+            }
+        }
+    }
+    dst[((int64_t)z * H + y) * W + x] = acc;
+}
+
+__global__ void __launch_bounds__(AUG_T) k_sim_remap(int64_t n, const SimTables* __restrict__ T, float* __restrict__ t1w,
+                                                      const float* __restrict__ tissue, const float* __restrict__ label,
+                                                      float* __restrict__ partial) {
+    __shared__ float red[2][AUG_T / 64];
+    const int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
+    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+    if (i < n) {
+        const float x = t1w[i];
+        float out = 0.f;
+        if (!(x <= 0.02f)) {
+            const float z = tissue[i], rx = 1.0f - x, rz = 1.0f - z;
+            const float px[4] = {1.0f, x, x * x, x * x * x}, pz[4] = {1.0f, z, z * z, z * z * z};
+            const float qx[4] = {1.0f, rx, rx * rx, rx * rx * rx}, qz[4] = {1.0f, rz, rz * rz, rz * rz * rz};
+            float s = 0.f;
+            for (int k = 0; k < UNET_SIM_TERMS; ++k) {
+                // selects instead of indexing the small arrays with run-time exponents (that would put them in scratch)
+                const int a = T->ta[k], b = T->tb[k], c = T->tc[k], d = T->td[k];
+                const float fa = a == 0 ? px[0] : a == 1 ? px[1] : a == 2 ? px[2] : px[3];
+                const float fb = b == 0 ? pz[0] : b == 1 ? pz[1] : b == 2 ? pz[2] : pz[3];
+                const float fc = c == 0 ? qx[0] : c == 1 ? qx[1] : c == 2 ? qx[2] : qx[3];
+                const float fd = d == 0 ? qz[0] : d == 1 ? qz[1] : d == 2 ? qz[2] : qz[3];
+                s += T->term_w[k] * fa * fb * fc * fd;
+            }
+            out = powf(s, T->gamma);
+            if (!T->with_label || label[i] != 0.f) { mn = out; mx = out; }     // train.cpp:105-109 / :168-169
+        }
+        t1w[i] = out;
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mn; red[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < AUG_T / 64; ++k) { mn = fminf(mn, red[0][k]); mx = fmaxf(mx, red[1][k]); }
+        mn = fminf(mn, red[0][0]); mx = fmaxf(mx, red[1][0]);
+        partial[2 * (size_t)blockIdx.x] = mn;
+        partial[2 * (size_t)blockIdx.x + 1] = mx;
+    }
+}
+
+__global__ void __launch_bounds__(CELLS_T) k_sim_minmax(const float* __restrict__ partial, unsigned n_blocks, float* __restrict__ mm) {
+    __shared__ float red[2][CELLS_T / 64];
+    float mn = 3.402823466e+38f, mx = -3.402823466e+38f;
+    for (unsigned i = threadIdx.x; i < n_blocks; i += CELLS_T) { mn = fminf(mn, partial[2 * (size_t)i]); mx = fmaxf(mx, partial[2 * (size_t)i + 1]); }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mn; red[1][threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < CELLS_T / 64; ++k) { mn = fminf(mn, red[0][k]); mx = fmaxf(mx, red[1][k]); }
+        mm[0] = mn; mm[1] = mx;
+    }
+}
+
+__global__ void __launch_bounds__(AUG_T) k_sim_final(int64_t n, const float* __restrict__ mm, float* __restrict__ t1w) {
+    const int64_t i = (int64_t)blockIdx.x * AUG_T + threadIdx.x;
+    if (i >= n) return;
+    const float mn = mm[0], mx = mm[1];
+    if (!(mx > mn)) return;
+    const float inv = 1.0f / (mx - mn);
+    float v = (t1w[i] - mn) * inv;                       // t1w -= mn; t1w *= 1/(mx-mn), train.cpp:112-113
+    t1w[i] = fminf(fmaxf(v, 0.f), 1.0f);                 // tipl::upper_lower_threshold(t1w, 0, 1)
+}
+
+}  // namespace
+
+size_t simulate_scratch_bytes(const UnetSimulateRecipe& r) {
+    const size_t n = (size_t)r.dims[0] * r.dims[1] * r.dims[2];
+    const size_t nb = (n + AUG_T - 1) / AUG_T;
+    return aug_align(sizeof(SimTables)) + 2 * aug_align(n * sizeof(float)) + aug_align(2 * nb * sizeof(float)) + 256;
+}
+
+void launch_simulate_modality(const UnetSimulateRecipe& r, float* t1w, const float* label, void* scratch, hipStream_t st) {
+    const int W = r.dims[0], H = r.dims[1], D = r.dims[2];
+    const int64_t n = (int64_t)W * H * D;
+    const unsigned nb = (unsigned)((n + AUG_T - 1) / AUG_T);
+    char* base = (char*)scratch;
+    SimTables* tab = (SimTables*)base; base += aug_align(sizeof(SimTables));
+    float* ta = (float*)base; base += aug_align(n * sizeof(float));
+    float* tb = (float*)base; base += aug_align(n * sizeof(float));
+    float* partial = (float*)base; base += aug_align(2 * (size_t)nb * sizeof(float));
+    float* mm = (float*)base;
+    SimTables t{};
+    for (int k = 0; k < UNET_SIM_MAX_LABELS; ++k) t.lut[k] = r.lut[k];
+    for (int k = 0; k < UNET_SIM_TERMS; ++k) {
+        t.term_w[k] = r.term_w[k]; t.ta[k] = r.term_a[k]; t.tb[k] = r.term_b[k]; t.tc[k] = r.term_c[k]; t.td[k] = r.term_d[k];
+    }
+    t.gamma = r.gamma; t.with_label = r.with_label; t.max_label = r.max_label;
+    k_sim_upload<<<1, 64, 0, st>>>(t, tab);
+    if (H > 4 * 65535 || D > 65535) throw std::runtime_error("unet_simulate_modality: height / depth beyond the launch grid");
+    const dim3 rows((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)D);
+    k_sim_smooth<true><<<rows, AUG_T, 0, st>>>(W, H, D, tab, r.with_label ? label : t1w, ta);
+    k_sim_smooth<false><<<rows, AUG_T, 0, st>>>(W, H, D, tab, ta, tb);
+    k_sim_remap<<<nb, AUG_T, 0, st>>>(n, tab, t1w, tb, label, partial);
+    k_sim_minmax<<<1, CELLS_T, 0, st>>>(partial, nb, mm);
+    k_sim_final<<<nb, AUG_T, 0, st>>>(n, mm, t1w);
+}
+
 }  // namespace unet
