@@ -619,9 +619,14 @@ static_assert(sizeof(SimTables) % 4 == 0, "word copy");
 template <bool FIRST>
 __global__ void __launch_bounds__(AUG_T) k_sim_smooth(int W, int H, int D, const SimTables* __restrict__ T, const float* __restrict__ src,
                                                        float* __restrict__ dst) {
+    __shared__ float lds_lut[UNET_SIM_MAX_LABELS];
+    const bool lut = FIRST && T->with_label;
+    if (lut) {   // 27 look-ups per voxel with data-dependent indices: from LDS, not from the table in global memory
+        for (int k = threadIdx.x; k < UNET_SIM_MAX_LABELS; k += AUG_T) lds_lut[k] = T->lut[k];
+        __syncthreads();
+    }
     int x, y, z;
     if (!row_voxel(W, H, x, y, z)) return;
-    const bool lut = FIRST && T->with_label;
     float acc = 0.f;
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
@@ -632,8 +637,8 @@ __global__ void __launch_bounds__(AUG_T) k_sim_smooth(int W, int H, int D, const
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int xx = min(max(x + kx - 1, 0), W - 1);
-                float v = src[((int64_t)zz * H + yy) * W + xx];
-                if (lut) v = T->lut[min(max((int)v, 0), T->max_label)];
+                float v = src[(unsigned)((zz * H + yy) * W + xx)];     // volumes < 2^31 voxels (checked by the launcher)
+                if (lut) v = lds_lut[min(max((int)v, 0), T->max_label)];
                 const float w = (float)((kz == 1 ? 2 : 1) * (ky == 1 ? 2 : 1) * (kx == 1 ? 2 : 1)) * (1.0f / 64.0f);
                 acc += w * v;
             }
@@ -729,7 +734,7 @@ void launch_simulate_modality(const UnetSimulateRecipe& r, float* t1w, const flo
     }
     t.gamma = r.gamma; t.with_label = r.with_label; t.max_label = r.max_label;
     k_sim_upload<<<1, 64, 0, st>>>(t, tab);
-    if (H > 4 * 65535 || D > 65535) throw std::runtime_error("unet_simulate_modality: height / depth beyond the launch grid");
+    if (H > 4 * 65535 || D > 65535 || n >= ((int64_t)1 << 31)) throw std::runtime_error("unet_simulate_modality: volume beyond the launch grid / 2^31 voxels");
     const dim3 rows((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)D);
     k_sim_smooth<true><<<rows, AUG_T, 0, st>>>(W, H, D, tab, r.with_label ? label : t1w, ta);
     k_sim_smooth<false><<<rows, AUG_T, 0, st>>>(W, H, D, tab, ta, tb);
