@@ -902,6 +902,7 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
         // loads in flight): the registers go straight into ds_write (a memory operation, which the "memory" clobber keeps behind the
         // wait), out-of-volume units are zeroed by a second ds_write to the same address, and the wait has no register operands
         // (tied operands made the compiler copy the registers BEFORE the wait on one path).
+        static_assert(ITERS == 3, "the vmcnt values below count 3 plane loads per step");
         auto wait_planes = [&](int younger_stores) {   // 0, 2 or 4 output stores are younger than the buffer, plus the other buffer's 3 loads
             if (younger_stores == 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else if (younger_stores == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
