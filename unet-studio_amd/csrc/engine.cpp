@@ -180,6 +180,14 @@ struct unet_plan {
                 b = wgrad_small_scratch_bytes(cg);
                 if (b > wmax) wmax = b;
             }
+            if (op.kind == OP_CONV && impl == UNET_IMPL_AUTO) {
+                SrcDesc sd[2];
+                for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
+                if (wgrad_f32_mfma_supported(dtype, cg, sd, op.nsrc)) {
+                    b = wgrad_f32_mfma_scratch_bytes(cg);
+                    if (b > wmax) wmax = b;
+                }
+            }
             if (op.kind == OP_CONV && cg.Cin == 1 && (cg.Cout == 16 || cg.Cout == 32)) {
                 b = conv_first_wgrad_mfma_scratch_bytes(cg);
                 if (b > wmax) wmax = b;
@@ -487,6 +495,8 @@ struct Exec {
                             launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else if (p.wgrad_mfma[i])
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+                        else if (p.impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
+                            launch_wgrad_f32_mfma(cg, sd, op.nsrc, (const float*)gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
                             launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else

@@ -189,6 +189,12 @@ void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mf
 bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
                           hipStream_t s);
+bool wgrad_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t wgrad_f32_mfma_scratch_bytes(const ConvGeom& g);
+void launch_wgrad_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* dy, float* dw, float* db, void* scratch,
+                           hipStream_t s);
+// out[i] += sum over the nsplit slabs of slab[k][i], fixed order, fp64 (kernels_direct.hip)
+void slab_reduce_public(const float* slab, int nsplit, int64_t n, float* out, hipStream_t s);
 bool conv_f32_mfma_dgrad_supported(int dtype, const ConvGeom& g, const DstGrad* dst, int ndst);
 void launch_conv_f32_mfma_dgrad(const ConvGeom& g, const float* dy, const float* w_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
 

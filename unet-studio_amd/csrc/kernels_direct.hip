@@ -350,6 +350,7 @@ static void slab_reduce2(const float* slab, int nsplit, int64_t n, float* out, i
     else k_slab_reduce_k<32><<<cdiv64(n, 32), 256, 0, s>>>(slab, nsplit, n, out, n1, out2);
 }
 static void slab_reduce(const float* slab, int nsplit, int64_t n, float* out, hipStream_t s) { slab_reduce2(slab, nsplit, n, out, n, nullptr, s); }
+void slab_reduce_public(const float* slab, int nsplit, int64_t n, float* out, hipStream_t s) { slab_reduce(slab, nsplit, n, out, s); }
 
 // bias grad: db[c] += sum over voxels of dy[v][c]; one block per channel
 template <typename T> __global__ void __launch_bounds__(256) k_bias_grad(const T* __restrict__ dy, int C, int64_t S, float* db, float* slab) {

@@ -225,4 +225,137 @@ void launch_conv_f32_mfma_dgrad(const ConvGeom& g, const float* dy, const float*
     else launch_f32_variant<1, 8, 8, 1>(a, s);
 }
 
+// ================================================================================================================
+// fp32 weight gradient of a stride-1 3x3x3 conv on the fp32 matrix cores:
+//   dW[tap][ci][co] = sum_v x[v + tap - 1][ci] * dy[v][co]        M = 16 ci, N = 16 co, K = 4 voxels of one x-row
+// grid = (persistent blocks over 2x8x16-voxel tiles, Cin/16, Cout/16); a block stages the 4x10x18 halo of its 16 input channels
+// ([voxel][16 ch]: the 4 voxels x 16 channels of an A operand fall on 64 different banks, with act(x*scale+shift) applied while
+// staging) and the tile's dy ([voxel][16 co]); wave w owns rows 4w..4w+3 and keeps all 27 tap accumulators (108 registers).
+// A dy operand is read once per 27 MFMAs.  Every wave writes its partial sums in the gradient's own layout to a slab of its own
+// (no atomics; fixed-order fp64 reduce, k_slab_reduce_k), so the result is bit-reproducible.
+// ================================================================================================================
+namespace {
+
+constexpr int W_BZ = 2, W_BY = 8, W_BX = 16, W_HZ = W_BZ + 2, W_HY = W_BY + 2, W_HX = W_BX + 2;
+constexpr int W_HV = W_HZ * W_HY * W_HX, W_TV = W_BZ * W_BY * W_BX;     // 720 halo voxels, 256 tile voxels
+
+struct WgradF32Args {
+    ConvGeom g;
+    SrcDesc s0, s1;
+    const float* dy;
+    float* slab;             // [gridDim.x * 4][27 * Cin * Cout]
+    int64_t total;           // 27 * Cin * Cout
+    int tz, ty, tx;
+};
+
+__global__ void __launch_bounds__(256) k_wgrad_f32_mfma(WgradF32Args a) {
+    extern __shared__ float lds[];
+    float* xs = lds;                       // [W_HV][16]
+    float* ds = lds + W_HV * 16;           // [W_TV][16]
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, lx = lane & 15, lq = lane >> 4;
+    const int ci0 = blockIdx.y * 16, co0 = blockIdx.z * 16;
+    const bool second = ci0 >= a.s0.C;
+    const float* sp = (const float*)(second ? a.s1.ptr : a.s0.ptr);
+    const int sC = second ? a.s1.C : a.s0.C, cb = second ? ci0 - a.s0.C : ci0;
+    const float* sc = second ? a.s1.scale : a.s0.scale;
+    const float* sh = second ? a.s1.shift : a.s0.shift;
+    const int act = second ? a.s1.act : a.s0.act;
+
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles = a.tz * a.ty * a.tx;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        int t = tile;
+        const int bx = t % a.tx; t /= a.tx;
+        const int by = t % a.ty, bz = t / a.ty;
+        const int z0 = bz * W_BZ, y0 = by * W_BY, x0 = bx * W_BX;
+        __syncthreads();   // the previous tile's MFMAs have read xs / ds
+        for (int it = tid; it < W_HV * 4; it += 256) {
+            const int hv = it >> 2, q = it & 3;
+            const int hz = hv / (W_HY * W_HX), rem = hv - hz * (W_HY * W_HX), hy = rem / W_HX, hx = rem - hy * W_HX;
+            const int iz = z0 + hz - 1, iy = y0 + hy - 1, ix = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+                const int c = cb + q * 4;
+                v = *(const float4*)(sp + (((int64_t)iz * g.H + iy) * g.W + ix) * sC + c);
+                if (sc) {
+                    const float4 s4 = *(const float4*)(sc + c), h4 = *(const float4*)(sh + c);
+                    v.x = v.x * s4.x + h4.x; v.y = v.y * s4.y + h4.y; v.z = v.z * s4.z + h4.z; v.w = v.w * s4.w + h4.w;
+                }
+                v.x = act_f(v.x, act); v.y = act_f(v.y, act); v.z = act_f(v.z, act); v.w = act_f(v.w, act);
+            }
+            *(float4*)(xs + hv * 16 + q * 4) = v;
+        }
+        for (int it = tid; it < W_TV * 4; it += 256) {
+            const int tv = it >> 2, q = it & 3;
+            const int tzz = tv / (W_BY * W_BX), rem = tv - tzz * (W_BY * W_BX), tyy = rem / W_BX, txx = rem - tyy * W_BX;
+            const int oz = z0 + tzz, oy = y0 + tyy, ox = x0 + txx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oz < g.Do && oy < g.Ho && ox < g.Wo)
+                v = *(const float4*)(a.dy + (((int64_t)oz * g.Ho + oy) * g.Wo + ox) * g.Cout + co0 + q * 4);
+            *(float4*)(ds + tv * 16 + q * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            const int row = wv * 4 + r, rz = row / W_BY, ry = row % W_BY;          // rows 0..15: (z, y) inside the tile
+#pragma unroll 1
+            for (int kk = 0; kk < 4; ++kk) {
+                const int xv = kk * 4 + lq;                                         // this lane's voxel (k index) along x
+                const float b = ds[((rz * W_BY + ry) * W_BX + xv) * 16 + lx];       // B[k = voxel][j = co]
+                const float* xp = xs + ((rz * W_HY + ry) * W_HX + xv) * 16 + lx;    // A[i = ci][k = voxel] at tap (0,0,0)
+#pragma unroll
+                for (int t = 0; t < 27; ++t) {
+                    const int kz = t / 9, ky = (t / 3) % 3, kx = t % 3;
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xp[((kz * W_HY + ky) * W_HX + kx) * 16], b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane (lq, lx) holds rows i = 4*lq + j (ci), column lx (co); torch layout index = (co*Cin + ci)*27 + tap
+    float* sl = a.slab + (size_t)(blockIdx.x * 4 + wv) * a.total;
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[((int64_t)(co0 + lx) * g.Cin + ci0 + 4 * lq + j) * 27 + t] = acc[t][j];
+}
+
+int wgrad_f32_blocks(const ConvGeom& g) {
+    const int64_t tiles = (int64_t)((g.Do + W_BZ - 1) / W_BZ) * ((g.Ho + W_BY - 1) / W_BY) * ((g.Wo + W_BX - 1) / W_BX);
+    const int64_t per_block = (int64_t)4 * 27 * g.Cin * g.Cout * 4;                // bytes of slabs one block column adds
+    int64_t nb = ((int64_t)64 << 20) / per_block;
+    if (nb < 1) nb = 1;
+    if (nb > 256) nb = 256;
+    return (int)(nb < tiles ? nb : tiles);
+}
+
+}  // namespace
+
+bool wgrad_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    if (dtype != 0 || g.ks != 3 || g.stride != 1 || g.Cin % 16 || g.Cout % 16 || nsrc < 1 || nsrc > 2) return false;
+    return src[0].C % 16 == 0 && (nsrc == 1 || src[1].C % 16 == 0);
+}
+size_t wgrad_f32_mfma_scratch_bytes(const ConvGeom& g) {
+    int64_t So = (int64_t)g.Do * g.Ho * g.Wo;
+    return (size_t)wgrad_f32_blocks(g) * 4 * 27 * g.Cin * g.Cout * 4 + bias_grad_scratch_bytes(g.Cout, So) + 512;
+}
+void launch_wgrad_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* dy, float* dw, float* db, void* scratch,
+                           hipStream_t s) {
+    WgradF32Args a;
+    a.g = g; a.s0 = src[0]; a.s1 = nsrc > 1 ? src[1] : SrcDesc();
+    if (nsrc == 1) a.s0.C = g.Cin;
+    a.dy = dy; a.slab = (float*)scratch; a.total = (int64_t)27 * g.Cin * g.Cout;
+    a.tz = (g.Do + W_BZ - 1) / W_BZ; a.ty = (g.Ho + W_BY - 1) / W_BY; a.tx = (g.Wo + W_BX - 1) / W_BX;
+    const int nb = wgrad_f32_blocks(g);
+    const size_t lds = (size_t)(W_HV * 16 + W_TV * 16) * sizeof(float);
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)k_wgrad_f32_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    k_wgrad_f32_mfma<<<dim3((unsigned)nb, (unsigned)(g.Cin / 16), (unsigned)(g.Cout / 16)), 256, lds, s>>>(a);
+    slab_reduce_public(a.slab, nb * 4, a.total, dw, s);
+    if (db) launch_bias_grad(0, dy, g.Cout, (int64_t)g.Do * g.Ho * g.Wo, db, (char*)scratch + (size_t)nb * 4 * a.total * 4 + 256, s);
+}
+
 }  // namespace unet
