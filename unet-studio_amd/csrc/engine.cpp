@@ -858,6 +858,12 @@ int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes)
         if (w > b) b = w;
     }
     if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {
+        ConvGeom gf;   // fp32 matrix-core wgrad: per-wave slabs (<= 64 MB) + the bias partials
+        gf.Cin = cin; gf.Cout = cout; gf.D = gf.Do = D; gf.H = gf.Ho = H; gf.W = gf.Wo = W; gf.ks = 3; gf.stride = 1;
+        size_t wf32 = wgrad_f32_mfma_scratch_bytes(gf);
+        if (wf32 > b) b = wf32;
+    }
+    if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {
         ConvGeom g;   // MFMA wgrad slabs: stride-1 geometry has the most tiles
         g.Cin = cin; g.Cout = cout; g.D = g.Do = D; g.H = g.Ho = H; g.W = g.Wo = W; g.ks = 3; g.stride = 1;
         size_t w = mfma_wgrad_scratch_bytes(g);
@@ -988,6 +994,8 @@ int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy
             launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
         else if (impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(dtype, g, &sd, 1))
             launch_conv_first_wgrad_mfma(g, &sd, dy, dw, db, scratch, (hipStream_t)stream);
+        else if (impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(dtype, g, &sd, 1))
+            launch_wgrad_f32_mfma(g, &sd, 1, (const float*)dy, dw, db, scratch, (hipStream_t)stream);
         else if (impl == UNET_IMPL_AUTO && wgrad_small_supported(g, 1))
             launch_conv_wgrad_small(dtype, g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
         else
