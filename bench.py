@@ -3,17 +3,28 @@
 backward + /batch_size + clip_grad_norm_(12) + SGD-Nesterov) on synthetic 128^3 single-channel volumes, bf16
 activations / fp32 master weights, default architecture (train.cpp:1054-1069), in=1, out=6.
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by torch.distributed.run (one rank per GPU: RANK / LOCAL_RANK / WORLD_SIZE in the environment), or --
+with WORLD_SIZE unset -- this script starts its N ranks itself as fresh child processes (before anything touches the GPU in
+the parent), the way train_unet::start spawns one worker per visible device (train.cpp:581-606,962-971).
 
 One "step" = one optimizer step with batch_size = N (one 128^3 sample per GPU per step, weak scaling): the flat fp32
-gradient buffer is summed over ranks with one RCCL all-reduce, then every rank applies the identical update.
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the heaviest conv3d of the step), timed live
-with HIP events on the launch stream; `cpu_baseline` is the ATen-CPU executor of oracle/aten_ref.py (the reference's
-CPU path = libtorch CPU kernels in unet.cpp order) on a bounded sample, rank 0, N=1 only.
+gradient buffer is summed over ranks with RCCL all-reduces (in buckets, under the backward), then every rank applies the
+identical update.  Rank 0 prints ONE JSON line:
+  * `roofline`        the launch with the largest share of the step's conv kernel time (found live: every op of three profiled
+                      steps is bracketed by HIP events on its launch stream, unet_profile_begin/end), algorithmic FLOPs / its time;
+  * `conv_mfma_frac`  conv forward + dgrad + wgrad FLOPs of the step / the summed time of those kernels / the bf16 MFMA peak
+                      (north_star: >= 40 % on conv3d fwd+bwd), next to `step_mfma_frac` (same FLOPs / the whole step's wall time);
+  * `roofline_kernels` micro-benchmarks through the single-op C ABI of the heaviest forward conv and the heaviest weight gradient;
+  * `cpu_baseline`    the ATen-CPU executor of oracle/aten_ref.py (the reference's CPU path = libtorch CPU kernels in unet.cpp
+                      order) on a bounded sample, rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,11 +35,24 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_MATRIX = 157.3e12
-PEAK_HBM = 8.0e12
+PEAK_HBM = 8.0e12    # spec; ~6.3e12 achievable (MI355X_MICROARCH.md, HBM)
+
+
+def _time_launches(run, iters):
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
 
 
 def dominant_kernel(U, size, dtype_name, iters=20):
-    """Times the heaviest conv3d of the step (decode0.0: 32->16 @ size^3, 3x3x3) as launched through the C ABI.
+    """Times the heaviest forward conv3d of the step (decode0.0: 32->16 @ size^3, 3x3x3) as launched through the C ABI.
     Returns (algorithmic flops per launch, avg seconds per launch)."""
     import ctypes as C
     E = U.engine
@@ -59,28 +83,46 @@ def dominant_kernel(U, size, dtype_name, iters=20):
         def run():
             E.check(E.lib.unet_op_conv3d_fwd(edt, U.IMPL_AUTO, x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), cin, cout, D, H, W,
                                              3, 1, sc.data_ptr(), st))
-    for _ in range(10):
-        run()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    sec = _time_launches(run, iters)
     flops = 2.0 * cin * cout * 27 * D * H * W
     return flops, sec
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950, + WRITE_SIZE), recorded by profiles/collect_traffic.sh into profiles/dominant_kernel_traffic.json."""
+def dominant_wgrad(U, size, dtype_name, cin=32, cout=16, iters=20):
+    """The heaviest weight gradient of the step (decode0.0: dW of conv3d cin->cout 3x3x3 @ size^3) through
+    unet_op_conv3d_bwd_weight: the wgrad kernel + its slab reduce, as a plan launches them."""
+    import ctypes as C
+    E = U.engine
+    D = H = W = size
+    dt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    edt = U.DTYPE_BF16 if dtype_name == "bf16" else U.DTYPE_F32
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = torch.randn((D, H, W, cin), device=dev).to(dt)
+    dy = torch.randn((D, H, W, cout), device=dev).to(dt)
+    dw = torch.zeros((cout, cin, 3, 3, 3), device=dev)
+    db = torch.zeros(cout, device=dev)
+    nb = C.c_size_t()
+    E.check(E.lib.unet_op_scratch_bytes(cin, cout, D, H, W, C.byref(nb)))
+    sc = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def run():
+        E.check(E.lib.unet_op_conv3d_bwd_weight(edt, U.IMPL_AUTO, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), cin, cout,
+                                                D, H, W, 3, 1, sc.data_ptr(), st))
+    sec = _time_launches(run, iters)
+    return 2.0 * cin * cout * 27 * D * H * W, sec
+
+
+def recorded_traffic(name):
+    """HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE),
+    RECORDED by profiles/collect_traffic.sh into profiles/<name>.json -- not a measurement of this run; returned with its source."""
+    path = os.path.join("profiles", name + ".json")
     try:
-        with open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, path)) as f:
+            d = json.load(f)
+        return d.get("hbm_bytes_per_launch"), "recorded: %s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; %s)" % (path, d.get("kernel", "?"))
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(size, budget_steps=3):   # ~3 s per 128^3 step on 16 cores: 1 warm-up + 3 timed steps = ~12 s of CPU work
@@ -114,6 +156,94 @@ def cpu_baseline(size, budget_steps=3):   # ~3 s per 128^3 step on 16 cores: 1 w
             "ms_per_step": dt * 1e3}
 
 
+def op_flops(o):
+    """algorithmic 2*MAC of one conv / conv_trans op (forward = dgrad = wgrad)"""
+    if o["kind"] == 1:
+        v = o["out_dims"][0] * o["out_dims"][1] * o["out_dims"][2]
+        return 2.0 * o["ks"] ** 3 * o["cin"] * o["cout"] * v
+    if o["kind"] == 2:
+        v = o["in_dims"][0] * o["in_dims"][1] * o["in_dims"][2]
+        return 2.0 * 8 * o["cin"] * o["cout"] * v
+    return 0.0
+
+
+def profile_steps(U, trainer, plan, peak, nsteps=3):
+    """Per-op HIP-event brackets (include/unet_hip.h: unet_profile_begin/end) over `nsteps` optimizer steps: kernel time by family,
+    conv MFMA fraction, and the single launch with the largest share of the conv time."""
+    E = U.engine
+    trainer.step()
+    torch.cuda.synchronize()
+    with E.profile() as pr:
+        for _ in range(nsteps):
+            trainer.step()
+        torch.cuda.synchronize()
+    ops = plan.ops()
+    fam, per = {}, {}
+    for op, cat, ms in pr.records:
+        fam[cat] = fam.get(cat, 0.0) + ms / nsteps
+        per[(op, cat)] = per.get((op, cat), 0.0) + ms / nsteps
+    conv_ms = sum(fam.get(c, 0.0) for c in ("conv_fwd", "dgrad", "wgrad"))
+    flops = plan.flops_fwd + plan.flops_bwd
+    best = None
+    for (op, cat), ms in per.items():
+        if cat in ("conv_fwd", "dgrad", "wgrad") and op >= 0 and (best is None or ms > best[2]):
+            best = (op, cat, ms)
+    out = {"kernel_ms_by_family": {k: round(v, 4) for k, v in sorted(fam.items())},
+           "conv_kernel_ms": conv_ms, "conv_mfma_frac": flops / (conv_ms * 1e-3) / peak if conv_ms > 0 else None,
+           "profiled_steps": nsteps, "launch_brackets_per_step": len(pr.records) // nsteps}
+    if best is not None:
+        o = ops[best[0]]
+        fl = op_flops(o)
+        out["dominant"] = {"op": o["name"], "pass": best[1], "flops": fl, "ms": best[2],
+                           "share_of_conv_time": best[2] / conv_ms if conv_ms > 0 else None,
+                           "shape": "%d->%d k%d s%d @%s" % (o["cin"], o["cout"], o["ks"], o["stride"], "x".join(str(d) for d in o["out_dims"]))}
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """WORLD_SIZE unset and --gpus n > 1: be the launcher.  Nothing in this process has touched the GPU (device_count() does not
+    initialise it), the ranks are fresh children; rank 0 inherits stdout and prints the one JSON line."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit("bench.py --gpus %d: %d devices needed, %d visible -- one rank per GPU (train.cpp:962-971 builds one replica "
+                         "per visible device), ranks cannot share a device under RCCL" % (n, n, have))
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:      # a failed rank leaves the others stuck in a collective: end exactly our children
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if rc:
+        raise SystemExit("bench.py: a rank exited with code %d" % rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,19 +252,25 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event profile (roofline / conv_mfma_frac)")
     # BASELINE.json configs[4] (not the headline line): --size 256 --in-channels 2 --augment --no-cpu-baseline
     ap.add_argument("--in-channels", type=int, default=1)
     ap.add_argument("--augment", action="store_true", help="augment every sample on the GPU inside the timed step (unet_augment_run)")
+    ap.add_argument("--prefetch", action="store_true", help="with --augment: sample ring, sample i+1 is augmented on a side stream during step i")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a.gpus)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py --gpus %d: %d devices needed, %d visible" % (a.gpus, a.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     import torch.distributed as dist
@@ -149,15 +285,16 @@ def main():
     model = U.UNet3d(cin, 6, U.default_feature(6), device=dev, dtype=a.dtype, seed=0)
     if world > 1:  # same initial weights everywhere (the reference broadcasts every step: train.cpp:573-579)
         dist.broadcast(model.flat_params, 0)
-    param = U.TrainingParam(batch_size=world, epoch=max(10000, a.steps + a.warmup + 1), learning_rate=0.001)
+    param = U.TrainingParam(batch_size=world, epoch=max(10000, a.steps + a.warmup + 16), learning_rate=0.001)
     src = U.SyntheticVolumes(cin, 6, (n, n, n), dev, cache=4)   # samples resident in HBM before the timed region
     for i in range(world * 2):
         src(i % 4)
-    feed = src
+    feed = lambda i: src(i % 4)   # noqa: E731
     if a.augment:   # the resident template sample is augmented anew (seed = step-unique sample index) inside every timed step
-        aug = U.AugmentedVolumes(lambda i: src(i % 4))
-        feed = aug
-    trainer = U.Trainer(model, param, (lambda i: feed(i)) if a.augment else (lambda i: src(i % 4)), rank, world)
+        feed = U.AugmentedVolumes(lambda i: src(i % 4))
+        if a.prefetch and hasattr(U, "PrefetchedVolumes"):
+            feed = U.PrefetchedVolumes(feed, stride=world)
+    trainer = U.Trainer(model, param, feed, rank, world)
 
     def sync():
         if world > 1:
@@ -183,7 +320,6 @@ def main():
         vox = float(n) ** 3 * world * a.steps
         value = vox / dt
         step_flops = plan.flops_fwd + plan.flops_bwd
-        kflops, ksec = dominant_kernel(U, n, a.dtype)
         peak = PEAK_BF16 if a.dtype == "bf16" else PEAK_F32_MATRIX
         out = {
             "metric": "voxels/sec 3D U-Net train step @%d^3 %s" % (n, a.dtype), "value": value, "unit": "voxels/s", "n_gpus": world,
@@ -196,12 +332,37 @@ def main():
                        "global_batch": world, "volume": [n, n, n], "parallelism": "dp%d" % world,
                        "flops_per_step_per_sample": step_flops, "params": int(model.flat_params.numel())},
             "step_mfma_frac": (step_flops * world * a.steps / dt) / (peak * world),
-            "roofline": {"bound": "mfma", "achieved": kflops / ksec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": kflops / ksec / peak, "traffic": measured_traffic() if a.dtype == "bf16" else None,
-                         "kernel": "conv3d fwd 32->16 3x3x3 @%d^3 (decode0.0, 23.7%% of forward FLOPs)" % n,
-                         "avg_launch_ms": ksec * 1e3},
             "last_loss": loss,
         }
+        kernels = []
+        if world == 1 and not a.no_profile:
+            # (ranks > 1 would need the other ranks to join the profiled steps' collectives: the profile is a single-GPU measurement)
+            prof = profile_steps(U, trainer, plan, peak)
+            out["conv_mfma_frac"] = prof["conv_mfma_frac"]
+            out["conv_kernel_ms_per_step"] = prof["conv_kernel_ms"]
+            out["kernel_ms_by_family"] = prof["kernel_ms_by_family"]
+            d = prof.get("dominant")
+            if d:
+                out["roofline"] = {"bound": "mfma", "achieved": d["flops"] / (d["ms"] * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                                   "frac": d["flops"] / (d["ms"] * 1e-3) / peak, "traffic": None,
+                                   "kernel": "%s of %s (%s): the launch with the largest share of the step's conv kernel time (%.1f %%), "
+                                             "HIP events around it inside %d profiled steps"
+                                             % (d["pass"], d["op"], d["shape"], 100.0 * d["share_of_conv_time"], prof["profiled_steps"]),
+                                   "avg_launch_ms": d["ms"]}
+        if n == 128 and cin == 1:
+            kflops, ksec = dominant_kernel(U, n, a.dtype)
+            tr_b, tr_src = recorded_traffic("dominant_kernel_traffic") if a.dtype == "bf16" else (None, None)
+            kernels.append({"kernel": "conv3d fwd 32->16 3x3x3 @%d^3 (decode0.0, 23.7%% of forward FLOPs), unet_op_conv3d_fwd_packed" % n,
+                            "bound": "mfma", "achieved": kflops / ksec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": kflops / ksec / peak,
+                            "avg_launch_ms": ksec * 1e3, "traffic": tr_b, "traffic_source": tr_src})
+            wflops, wsec = dominant_wgrad(U, n, a.dtype)
+            tr_b, tr_src = recorded_traffic("wgrad_kernel_traffic") if a.dtype == "bf16" else (None, None)
+            kernels.append({"kernel": "conv3d wgrad 32->16 3x3x3 @%d^3 (decode0.0) + slab reduce, unet_op_conv3d_bwd_weight" % n,
+                            "bound": "mfma", "achieved": wflops / wsec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": wflops / wsec / peak,
+                            "avg_launch_ms": wsec * 1e3, "traffic": tr_b, "traffic_source": tr_src})
+            out["roofline_kernels"] = kernels
+            if "roofline" not in out:
+                out["roofline"] = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)

@@ -106,6 +106,7 @@ public:
     void prepare_for_inference(const torch::Device& device);
 
 public: // ---- engine side (not in the reference) ----
+    size_t pooled_workspaces(void) const;   // idle workspaces held by the pool (tests: bounded under fresh-thread callers)
     int engine_dtype = 1;                  // UNET_DTYPE_BF16 (0 = fp32 parity configuration)
     torch::Tensor flat_params, flat_grads; // fp32, parameters() order; the registered parameters are views
     void to_device(const torch::Device& device);   // what to(device) means for the flat storage
@@ -116,11 +117,15 @@ private:
     friend struct UNetForwardFn;
     std::vector<torch::Tensor> params_, buffers_;
     std::map<std::array<int64_t,3>, unet_plan*> plans_;
-    std::map<std::pair<unet_plan*, size_t>, torch::Tensor> workspaces_;   // (plan, thread) -> workspace
+    // Workspaces are leased per call from a small pool and go back when the call's last user is done (the no-grad forward on
+    // return, the training forward when its autograd node has run backward or is dropped): train.cpp:592-594 starts fresh
+    // std::threads every optimizer step, so nothing may be keyed by thread id; qc.cpp:273-297 runs up to 4 forwards at once.
+    struct WorkspacePool;
+    std::shared_ptr<WorkspacePool> ws_pool_;
     std::mutex plans_mutex_;
     torch::Tensor trigger_, momentum_, scratch_;
     unet_plan* plan_for(int64_t d,int64_t h,int64_t w);
-    torch::Tensor workspace_for(unet_plan* plan);
+    torch::Tensor workspace_for(unet_plan* plan);   // a lease: returns itself to the pool when the last reference goes away
     void bind_views(void);
     void ensure_flat(void);
     void rebind_grads(void);

@@ -73,6 +73,25 @@ int unet_plan_flops(const unet_plan* plan, double* fwd, double* bwd);
 /* human-readable op list of the lowered graph (for print_layers()/debugging); returns needed length */
 size_t unet_plan_describe(const unet_plan* plan, char* buf, size_t len);
 
+/* lowered op list (forward order): kind 0 pack_input, 1 conv, 2 conv_trans, 3 norm, 4 materialize, 5 max_pool, 6 upsample,
+ * 7 export; dims are {D,H,W} of the first source / the destination tensor (0 where there is none) */
+int unet_plan_op_count(const unet_plan* plan, int* n);
+int unet_plan_op_info(const unet_plan* plan, int i, int* kind, int* cin, int* cout, int* ks, int* stride, int64_t in_dims[3],
+                      int64_t out_dims[3], char* name, size_t name_len);
+
+/* Per-op timing for the measurement harness (bench.py: conv_mfma_frac, the time-dominant kernel).  Between begin and end every
+ * unet_forward / unet_backward issued by THIS host thread runs on the caller's stream only and brackets each op's launches with
+ * HIP events; end synchronises and returns one record per bracket: the op index (-1: the batched filter pack), a category and
+ * the elapsed milliseconds.  No reference counterpart (the reference has no profiler). */
+#define UNET_PROF_CONV_FWD 0 /* conv / conv_trans forward kernels (+ their per-op filter packs) */
+#define UNET_PROF_DGRAD 1    /* input-gradient kernels */
+#define UNET_PROF_WGRAD 2    /* weight/bias-gradient kernels and their slab reduces */
+#define UNET_PROF_NORM_FWD 3 /* norm finalize + activated copy */
+#define UNET_PROF_NORM_BWD 4 /* norm / activation backward */
+#define UNET_PROF_OTHER 5    /* input pack, pool, upsample, heads' backward, export, batched filter pack */
+int unet_profile_begin(void);
+int unet_profile_end(int max_records, int* op_index, int* category, float* ms, int* n_records);
+
 /* forward.  params: host array of device pointers (fp32, parameters() order).  buffers: host array of
  * device pointers (fp32 running_mean/running_var pairs) or NULL when the architecture has no bnorm.
  * x: fp32 {1,in_c,D,H,W}.  outs: host array of device pointers, fp32 {1,out_c,D>>l,H>>l,W>>l} per level

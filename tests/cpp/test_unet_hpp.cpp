@@ -2,7 +2,10 @@
 // with the same torch::nn modules, in the same order, as the reference's unet.cpp:24-193 builds for this DSL string.
 // Exit code 0 and "OK" on success.  Usage: test_unet_hpp [fp32|bf16]
 #include "unet.hpp"
+#include <c10/hip/HIPCachingAllocator.h>
+#include <atomic>
 #include <iostream>
+#include <thread>
 
 static double rel(const torch::Tensor& a, const torch::Tensor& b) {
     auto A = a.to(torch::kCPU).to(torch::kFloat64), B = b.to(torch::kCPU).to(torch::kFloat64);
@@ -109,6 +112,52 @@ int main(int argc, char** argv) {
     auto before = model->flat_grads.clone();
     model->add_gradient_from(*replica);
     REQUIRE(rel(model->flat_grads, before + replica->flat_grads) < 1e-6, "add_gradient_from");
+    // ---- workspace pool (train.cpp:592-594: fresh std::threads every optimizer step; qc.cpp:273-297: 4 workers on one model) ----
+    {
+        auto reserved = [&]() {
+            torch::cuda::synchronize();
+            return (long long)c10::hip::HIPCachingAllocator::getDeviceStats(0).reserved_bytes[0].current;
+        };
+        replica->train();
+        auto xd = x.to(dev), wd = w.to(dev);
+        std::atomic<int> failures{0};
+        auto micro_step = [&]() {   // what a GPU thread of train.cpp does with its replica: forward, loss, backward
+            try {
+                auto o = replica->forward(xd);
+                (o[0] * wd).sum().backward();
+            } catch (const std::exception& e) { std::cerr << e.what() << std::endl; ++failures; }
+        };
+        for (int i = 0; i < 3; ++i) { std::thread t(micro_step); t.join(); }    // warm the allocator and the pool
+        const long long r0 = reserved();
+        const size_t idle0 = replica->pooled_workspaces();
+        for (int i = 0; i < 20; ++i) { std::thread t(micro_step); t.join(); }    // 20 micro-steps, each from a FRESH thread
+        REQUIRE(failures == 0, "micro-step from a fresh thread threw");
+        REQUIRE(reserved() == r0, "device memory grew under fresh-thread callers: " + std::to_string(reserved() - r0) + " bytes");
+        REQUIRE(replica->pooled_workspaces() == idle0 && idle0 >= 1 && idle0 <= 4, "pool size " + std::to_string(replica->pooled_workspaces()));
+        // a forward whose outputs are dropped without backward still returns its lease
+        { auto o = replica->forward(xd); }
+        REQUIRE(replica->pooled_workspaces() == idle0, "lease of an unused training forward was not returned");
+        // 4 concurrent eval forwards on ONE model (qc.cpp:273-297) agree with a serial one, and the pool stays bounded
+        model->eval();
+        torch::Tensor serial;
+        { torch::NoGradGuard ng; serial = model->forward(xd)[0].clone(); }
+        std::vector<torch::Tensor> got(4);
+        std::vector<std::thread> th;
+        for (int k = 0; k < 4; ++k)
+            th.emplace_back([&, k]() {
+                try {
+                    torch::NoGradGuard ng;
+                    torch::Tensor last;
+                    for (int r = 0; r < 5; ++r) last = model->forward(xd)[0];
+                    got[k] = last.clone();
+                } catch (const std::exception& e) { std::cerr << e.what() << std::endl; ++failures; }
+            });
+        for (auto& t : th) t.join();
+        torch::cuda::synchronize();
+        REQUIRE(failures == 0, "concurrent eval forward threw");
+        for (int k = 0; k < 4; ++k) REQUIRE(got[k].defined() && torch::equal(got[k], serial), "concurrent eval forward " + std::to_string(k) + " differs");
+        REQUIRE(model->pooled_workspaces() <= 4, "pool exceeds its bound");
+    }
     std::cout << model->get_info();
     std::cout << "OK " << (bf16 ? "bf16" : "fp32") << " logits rel " << rel(outs[0], yr) << std::endl;
     return 0;

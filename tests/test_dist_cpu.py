@@ -64,6 +64,18 @@ class CpuStandInModel:
         self.flat_grads += torch.cat([p.grad.flatten() for p in self.ref.parameters()])
         return torch.stack([loss.detach(), *st])
 
+    def forward_backward_bucketed(self, x, t, on_bucket, ce=True, dice=True, mse=True):
+        """the engine's bucketed backward hands finished gradient ranges to the trainer from the END of the flat buffer down
+        (unet3d.py:forward_backward_bucketed); here the whole backward runs first, then the same two announcements"""
+        losses = self.forward_backward(x, t, ce, dice, mse)
+        n = int(self.flat_grads.numel())
+        on_bucket(n // 2, n)
+        on_bucket(0, n // 2)
+        return losses
+
+    def buffers(self):
+        return list(self.ref.buffers())
+
     def flat_params(self):
         return torch.cat([p.detach().flatten() for p in self.ref.parameters()])
 
@@ -111,6 +123,25 @@ def test_two_rank_step_equals_single_rank():
     assert np.allclose(p0, ref, rtol=1e-5, atol=1e-6)
     assert np.allclose(s0, sref, rtol=1e-5, atol=1e-6)      # summed loss statistics, train.cpp:732-741
     assert np.allclose(s0, s1)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("batch", [1, 3])
+def test_two_ranks_with_uneven_or_missing_samples(batch):
+    """batch_size < world_size leaves rank 1 without a micro-step (the reference starts min(gpus, batch_size) threads,
+    train.cpp:581-582), batch 3 gives rank 0 two and rank 1 one: every rank must still issue the same collectives, in the same
+    order and of the same sizes, and end with the single-rank parameters."""
+    steps = 2
+    single = {}
+    _run(0, 1, 0, steps, batch, single)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run, args=(2, _free_port(), steps, batch, out), nprocs=2, join=True)
+    p0, s0 = out[0]
+    p1, s1 = out[1]
+    assert np.array_equal(p0, p1)
+    assert np.allclose(p0, single[0][0], rtol=1e-5, atol=1e-6)
+    assert np.allclose(s0, single[0][1], rtol=1e-5, atol=1e-6) and np.allclose(s0, s1)
 
 
 def test_lr_schedule_matches_reference():

@@ -497,6 +497,50 @@ def test_full_size_128_properties(dt):
     assert abs(fd - an) < 0.25 * max(abs(an), 1e-3), (fd, an)
 
 
+@pytest.mark.timeout(900)
+def test_configs4_network_256_two_channels_augmented_bf16_step():
+    """BASELINE configs[4] on one GPU: default architecture, in = 2 (T1+T2), 256^3, bf16, every sample augmented on the device
+    (AugmentedVolumes -> unet_augment_run) and one Trainer.step().  No CPU reference finishes at this size, so the checks are
+    size-independent properties: (1) the whole optimizer step -- augmentation, forward, loss, backward, clip, SGD -- is bit
+    reproducible from the same state; (2) gradients and updated parameters are finite and non-zero; (3) the gradient agrees
+    with a central finite difference of the loss along itself (as test_full_size_128_properties)."""
+    n = 256
+    src = U.SyntheticVolumes(2, 6, (n, n, n), DEV, cache=1)
+    feed = U.AugmentedVolumes(lambda i: src(0))
+
+    def one_step():
+        m = U.UNet3d(2, 6, U.default_feature(6), device=DEV, dtype="bf16", seed=0)
+        tr = U.Trainer(m, U.TrainingParam(batch_size=1, epoch=100, learning_rate=0.01), feed)
+        stats = tr.step().clone()
+        torch.cuda.synchronize()
+        return m, stats, m.flat_params.clone(), float(m.optimizer.last_grad_norm)
+
+    m1, s1, p1, gn1 = one_step()
+    init = U.UNet3d(2, 6, U.default_feature(6), device=DEV, dtype="bf16", seed=0).flat_params.clone()
+    del m1
+    m2, s2, p2, gn2 = one_step()
+    assert torch.equal(s1, s2) and torch.equal(p1, p2) and gn1 == gn2, "the 256^3 augmented step is not bit reproducible"
+    assert torch.isfinite(p1).all() and torch.isfinite(s1).all() and np.isfinite(gn1) and gn1 > 0
+    assert float((p1 - init).abs().max()) > 0, "the step did not move the parameters"
+    assert 0.5 < float(s1[0]) < 20.0                      # 5-level CE + Dice + MSE of an untrained 6-class net
+    # gradient vs finite difference on the augmented sample (m2 now holds the post-step weights; any point works)
+    x, t = feed(0)
+    assert x.shape == (1, 2, n, n, n) and t.shape == (1, n, n, n) and int(t.max()) < 6
+    m2.flat_grads.zero_()
+    m2.forward_backward(x, t)
+    g = m2.flat_grads.clone()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    dvec = g / g.norm()
+    eps = 2e-2
+    with torch.no_grad():
+        m2.flat_params.add_(eps * dvec); m2._params_version += 1
+        lp = float(m2.loss(m2.forward(x), t, want_grad=False)[0][0])
+        m2.flat_params.add_(-2 * eps * dvec); m2._params_version += 1
+        lm = float(m2.loss(m2.forward(x), t, want_grad=False)[0][0])
+    fd, an = (lp - lm) / (2 * eps), float((g * dvec).sum())
+    assert abs(fd - an) < 0.25 * max(abs(an), 1e-3), (fd, an)
+
+
 # ---- the two forward-only callers of the path: evaluate.cpp:211-246 (a22) and the validation thread train.cpp:826-852 (a23) ----
 ARCH_BN_EVAL = ("conv8,ks3,stride1+bnorm,relu+conv8,ks3,stride1+bnorm,relu\n"
                 "max_pool+conv16,ks3,stride1+bnorm,relu+conv16,ks3,stride1+bnorm,relu+conv_trans8,ks2,stride2\n"

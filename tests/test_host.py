@@ -94,3 +94,28 @@ def test_lowered_graph_fuses_norm_and_activation():
     assert "materialize" not in d          # every norm/act of the default architecture is read-fused
     assert d.count("=> results[") == 5     # 5 heads write forward()'s results directly
     assert "src[t2+norm+leaky_relu,t29]" in d  # cat(skip, x) is a dual-source read, never materialised
+
+
+def test_bench_launches_its_own_ranks_and_names_the_missing_devices():
+    """bench.py --gpus N without WORLD_SIZE is its own launcher (train.cpp:581-606 starts one worker per device): with fewer
+    than N devices it must stop with a message that says so -- not ask for torch.distributed.run -- and a non-zero exit code."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "64 devices needed" in (r.stderr + r.stdout)
+    assert "torch.distributed.run" not in (r.stderr + r.stdout)
+
+
+def test_plan_op_list_names_every_conv_of_the_default_arch():
+    p = U.Plan(A.default_feature(6), 1, 6, (128, 128, 128))
+    ops = p.ops()
+    convs = [o for o in ops if o["kind"] in (1, 2)]
+    assert len(convs) == 22 + 5 + 5          # 22 3x3x3 convs, 5 heads, 5 conv_trans
+    fl = 0.0
+    for o in convs:
+        v = o["out_dims"] if o["kind"] == 1 else o["in_dims"]
+        fl += 2.0 * (o["ks"] ** 3 if o["kind"] == 1 else 8) * o["cin"] * o["cout"] * v[0] * v[1] * v[2]
+    assert abs(fl - p.flops_fwd) < 1e-6 * p.flops_fwd

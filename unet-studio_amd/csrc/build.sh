@@ -12,9 +12,18 @@ for f in $SRCS; do
     o=build/${f%.*}.o
     if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then todo="$todo $f"; fi
 done
-if [ -n "$todo" ]; then
-    echo $todo | tr ' ' '\n' | xargs -P 6 -I{} sh -c 'f={}; hipcc '"$FLAGS"' -c "$f" -o build/${f%.*}.o'
+[ -f ../conv_z_check.json ] || todo="$todo conv_z_check"
+todo_src=$(echo $todo | tr ' ' '\n' | grep -v '^conv_z_check$' | tr '\n' ' ')
+if [ -n "$(echo $todo_src | tr -d ' ')" ]; then
+    echo $todo_src | tr ' ' '\n' | xargs -P 6 -I{} sh -c 'f={}; hipcc '"$FLAGS"' -c "$f" -o build/${f%.*}.o'
 fi
+# k_mfma_conv_z waits for inline-asm loads with hand-counted vmcnt values: check the emitted code whenever its file was rebuilt
+# (tools/check_conv_z.py: no scratch, the expected memory operations, no instruction touching a load's registers in flight)
+case " $todo " in *" kernels_mfma_conv.hip "*|*" conv_z_check "*)
+    hipcc $FLAGS --cuda-device-only -S kernels_mfma_conv.hip -o build/kernels_mfma_conv.s 2>/dev/null
+    python3 tools/check_conv_z.py build/kernels_mfma_conv.s ../conv_z_check.json || { rm -f build/kernels_mfma_conv.o; exit 1; }
+    ;;
+esac
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS build/${f%.*}.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../libunet_hip.so $OBJS

@@ -39,6 +39,29 @@ struct DeviceGuard {
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// ---- per-op timing (unet_profile_begin / unet_profile_end) ----
+// While a host thread has a profile open, every forward / backward it issues runs on the caller's stream alone (no side
+// stream) and each op's launches are bracketed by a pair of HIP events on that stream, tagged (op index, category).
+struct ProfRec { int op, cat; hipEvent_t e0, e1; };
+struct ProfSink { std::vector<ProfRec> recs; };
+thread_local ProfSink* g_prof = nullptr;
+struct ProfScope {
+    ProfRec r{};
+    hipStream_t s = nullptr;
+    bool on = false;
+    ProfScope(int op, int cat, hipStream_t st) {
+        if (!g_prof) return;
+        on = true; s = st; r.op = op; r.cat = cat;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.e0, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, s);
+        g_prof->recs.push_back(r);
+    }
+};
+
 }  // namespace
 
 struct unet_plan {
@@ -291,13 +314,14 @@ struct Exec {
                 // fp32 filter) and its norm; the first kernel that needs packed filters waits for it.  (Eval forwards stay on the
                 // caller's stream: they are re-entrant per workspace, the side stream and its events are per plan.)
                 static const bool no_side = getenv("UNET_NO_SIDE_STREAM") != nullptr;
-                if (mode == 1 && p.side && !no_side) {
+                if (mode == 1 && p.side && !no_side && !g_prof) {
                     HIP_OK(hipEventRecord(p.ev_fork, s));
                     HIP_OK(hipStreamWaitEvent(p.side, p.ev_fork, 0));
                     launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, p.side);
                     HIP_OK(hipEventRecord(p.ev_join, p.side));
                     pack_pending = true;
                 } else {
+                    ProfScope ps(-1, UNET_PROF_OTHER, s);
                     launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, s);
                 }
                 packed = true;
@@ -308,6 +332,7 @@ struct Exec {
         };
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
+            ProfScope ps((int)i, (op.kind == OP_CONV || op.kind == OP_CONVT) ? UNET_PROF_CONV_FWD : op.kind == OP_NORM ? UNET_PROF_NORM_FWD : UNET_PROF_OTHER, s);
             switch (op.kind) {
                 case OP_PACK_INPUT:
                     launch_pack_input(p.dtype, x, tptr(op.dst), g.in_c, g.tensors[op.dst].voxels(), s);
@@ -446,7 +471,7 @@ struct Exec {
         // sb: where the parameter-gradient kernels go.  fork() orders them after everything issued so far on the caller's stream
         // (dL/d(raw output) of the layer is final); the join at the end orders the caller's stream after them.
         static const bool no_side = getenv("UNET_NO_SIDE_STREAM") != nullptr;
-        const hipStream_t sb = (p.side && !no_side) ? p.side : s;
+        const hipStream_t sb = (p.side && !no_side && !g_prof) ? p.side : s;
         auto fork = [&]() {
             if (sb == s) return;
             HIP_OK(hipEventRecord(p.ev_fork, s));
@@ -470,6 +495,7 @@ struct Exec {
                 if (p.impl == UNET_IMPL_AUTO && head_supported(geom(op), op.nsrc)) {
                     // fused head backward: dL/dW, dL/db and dL/d(source view) in one pass over (source, dL/dresults[level])
                     DstGrad dgh = dst_of(op.src[0]);
+                    ProfScope ph(dry ? -2 : i, UNET_PROF_OTHER, s);
                     if (!dry) launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
                                     gparams[op.weight], gparams[op.bias], ws + p.head_off, s);
                     if (dgh.ptr) mark(op);
@@ -479,7 +505,7 @@ struct Exec {
                 init[t] = 1;
             }
             if (!g.tensors[t].needs_grad || !init[t]) continue;
-            if (!dry) view_backward(t, params, gparams);
+            if (!dry) { ProfScope ps(i, UNET_PROF_NORM_BWD, s); view_backward(t, params, gparams); }
             switch (op.kind) {
                 case OP_CONV:
                 case OP_CONVT: {
@@ -490,6 +516,7 @@ struct Exec {
                     bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
                     if (!dry) fork();
                     if (op.kind == OP_CONV) {
+                        ProfScope* pw = dry ? nullptr : new ProfScope(i, UNET_PROF_WGRAD, sb);
                         if (dry) {
                         } else if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc))
                             launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
@@ -501,17 +528,22 @@ struct Exec {
                             launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else
                             launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+                        delete pw;
+                        ProfScope pd(i, UNET_PROF_DGRAD, s);
                         if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (!dry && any && p.impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(p.dtype, cg, dg, op.nsrc))
                             launch_conv_f32_mfma_dgrad(cg, (const float*)gptr(t), wd, dg, op.nsrc, s);
                         else if (!dry && (any)) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
+                        ProfScope* pw = dry ? nullptr : new ProfScope(i, UNET_PROF_WGRAD, sb);
                         if (p.wgrad_mfma[i]) {
                             if (!dry) launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + p.wgrad_off, sb);
                             if (!dry) launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
                         } else {
                             if (!dry) launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         }
+                        delete pw;
+                        ProfScope pd(i, UNET_PROF_DGRAD, s);
                         if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (!dry && (any)) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     }
@@ -768,6 +800,47 @@ int unet_plan_backward_buckets(const unet_plan* p, int max_buckets, int* n_bucke
         *n_buckets = nb;
         return 0;
     } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int unet_plan_op_count(const unet_plan* p, int* n) { *n = (int)p->g.ops.size(); return 0; }
+int unet_plan_op_info(const unet_plan* p, int i, int* kind, int* cin, int* cout, int* ks, int* stride, int64_t in_dims[3],
+                      int64_t out_dims[3], char* name, size_t name_len) {
+    if (i < 0 || i >= (int)p->g.ops.size()) return fail("op index out of range");
+    const Op& op = p->g.ops[i];
+    if (kind) *kind = (int)op.kind;
+    if (cin) *cin = op.cin;
+    if (cout) *cout = op.cout;
+    if (ks) *ks = op.ks;
+    if (stride) *stride = op.stride;
+    const Tensor* a = op.nsrc > 0 && op.src[0] >= 0 ? &p->g.tensors[op.src[0]] : nullptr;
+    const Tensor* o = op.dst >= 0 ? &p->g.tensors[op.dst] : nullptr;
+    if (in_dims) { in_dims[0] = a ? a->D : 0; in_dims[1] = a ? a->H : 0; in_dims[2] = a ? a->W : 0; }
+    if (out_dims) { out_dims[0] = o ? o->D : 0; out_dims[1] = o ? o->H : 0; out_dims[2] = o ? o->W : 0; }
+    if (name && name_len) { std::strncpy(name, op.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    return 0;
+}
+
+int unet_profile_begin(void) {
+    if (g_prof) return fail("unet_profile_begin: a profile is already open on this thread");
+    g_prof = new ProfSink();
+    return 0;
+}
+int unet_profile_end(int max_records, int* op_index, int* category, float* ms, int* n_records) {
+    if (!g_prof) return fail("unet_profile_end: no open profile on this thread");
+    ProfSink* ps = g_prof;
+    g_prof = nullptr;
+    int n = 0, rc = 0;
+    for (auto& r : ps->recs) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(r.e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
+        if (e != hipSuccess) rc = fail(std::string("unet_profile_end: ") + hipGetErrorString(e));
+        if (r.op != -2 && n < max_records && op_index && category && ms) { op_index[n] = r.op; category[n] = r.cat; ms[n] = t; ++n; }
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    if (n_records) *n_records = n;
+    delete ps;
+    return rc;
 }
 
 int unet_loss_scratch_bytes(const unet_plan* p, size_t* bytes) { *bytes = p->loss_bytes; return 0; }

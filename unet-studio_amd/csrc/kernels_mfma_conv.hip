@@ -1007,6 +1007,8 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
             if (pe + 1 <= ze + 1) step(pe + 1, R2, std::integral_constant<int, 1>{});
         }
     }
+    // the last two steps prefetched past the end: those loads must land before the epilogue may reuse their registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.stats) {
         float* red = (float*)smem;
         __syncthreads();
@@ -1048,11 +1050,8 @@ static int launch_conv_z(const MfmaConvArgs& a0, hipStream_t s) {
     const int items = cols * nseg;
     const int gx = items < want ? items : want;
     constexpr int lds = 4 * 10 * 20 * 64;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_conv_z, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    set_max_lds_once(attr_done, (const void*)k_mfma_conv_z, lds);
     k_mfma_conv_z<<<dim3((unsigned)gx, (unsigned)gy), 256, lds, s>>>(a0, zw);
     return gx;
 }
@@ -1073,11 +1072,8 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
     constexpr size_t lds = tile_b + (KSTEPS * NT <= 32 ? (size_t)KSTEPS * NT * 1024 : 0);
     static_assert(tile_b >= NW * NT * 16 * 2 * 4, "stats scratch must fit the tile buffer");
     static_assert(lds <= 80 * 1024, "two blocks per CU");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    set_max_lds_once(attr_done, (const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW, false>, (int)lds);
     // persistent grid: at most ~2 blocks per CU in total (256 CUs), tiles strided over them
     const int tiles = a.tiles_x * a.tiles_y * a.tiles_z, gy = a.g.Cout / (16 * NT);
     // resident blocks per CU the LDS footprint allows, as a power of two (768-block grids measured 25 % slower than 512 / 1024)
@@ -1091,11 +1087,8 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
         // single-chunk layers (Cin == CK: 32->16 and 16->16 at 128^3): 4-wave blocks, <= 256 VGPRs, no spills
         // (measured against the 8-wave / 128-VGPR form: 0.087 -> 0.082 ms on the dominant layer, 4.16 -> 4.09 ms per step)
         if (a.g.Cin == CK) {
-            static bool attr4_done = false;
-            if (!attr4_done) {
-                (void)hipFuncSetAttribute((const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr4_done = true;
-            }
+            static std::atomic<uint64_t> attr4_done{0};
+            set_max_lds_once(attr4_done, (const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, 4, true>, (int)lds);
             k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, 4, true><<<grid, 256, lds, s>>>(a);
             return gx;
         }
@@ -1145,12 +1138,9 @@ template <int BZ, int BY, int BX> static int launch_small(const MfmaConvArgs& a0
     static_assert(SMALL_QS * tile_b <= 160 * 1024 && tile_b >= 16 * 1024, "LDS budget / reduction scratch");
     const int nchunk = a.g.Cin / 32, nq = nchunk < SMALL_QS ? nchunk : SMALL_QS;
     const size_t lds = (size_t)nq * tile_b;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_conv_small<BZ, BY, BX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMALL_QS * tile_b));
-        (void)hipFuncSetAttribute((const void*)k_mfma_conv_small<BZ, BY, BX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr1_done{0}, attr2_done{0};
+    set_max_lds_once(attr1_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 1>, (int)(SMALL_QS * tile_b));
+    set_max_lds_once(attr2_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 2>, 80 * 1024);
     const int tiles = a.tiles_x * a.tiles_y * a.tiles_z;
     dim3 grid((unsigned)tiles, (unsigned)(a.g.Cout / 16));
     if (lds <= 80 * 1024) k_mfma_conv_small<BZ, BY, BX, 2><<<grid, 256, lds, s>>>(a);   // two blocks per CU

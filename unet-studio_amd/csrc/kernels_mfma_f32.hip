@@ -162,8 +162,8 @@ bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, i
 template <int S, int BY, int CK, int NT> static void launch_f32_variant(ConvF32Args& a, hipStream_t s) {
     typedef F32Tile<S, BY, CK> TL;
     const size_t lds = TL::lds_bytes(NT);
-    static bool once = false;   // > 64 KB of dynamic LDS needs the opt-in
-    if (!once) { (void)hipFuncSetAttribute((const void*)k_conv_f32_mfma<S, BY, CK, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    static std::atomic<uint64_t> once{0};   // > 64 KB of dynamic LDS needs the opt-in, per device
+    set_max_lds_once(once, (const void*)k_conv_f32_mfma<S, BY, CK, NT>, (int)lds);
     a.tz = (a.g.Do + F_BZ - 1) / F_BZ; a.ty = (a.g.Ho + BY - 1) / BY; a.tx = (a.g.Wo + F_BX - 1) / F_BX;
     k_conv_f32_mfma<S, BY, CK, NT><<<dim3((unsigned)(a.tz * a.ty * a.tx), a.g.Cout / (16 * NT)), 256, lds, s>>>(a);
 }
@@ -351,8 +351,8 @@ void launch_wgrad_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, cons
     a.tz = (g.Do + W_BZ - 1) / W_BZ; a.ty = (g.Ho + W_BY - 1) / W_BY; a.tx = (g.Wo + W_BX - 1) / W_BX;
     const int nb = wgrad_f32_blocks(g);
     const size_t lds = (size_t)(W_HV * 16 + W_TV * 16) * sizeof(float);
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)k_wgrad_f32_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    static std::atomic<uint64_t> once{0};
+    set_max_lds_once(once, (const void*)k_wgrad_f32_mfma, (int)lds);
     k_wgrad_f32_mfma<<<dim3((unsigned)nb, (unsigned)(g.Cin / 16), (unsigned)(g.Cout / 16)), 256, lds, s>>>(a);
     slab_reduce_public(a.slab, nb * 4, a.total, dw, s);
     if (db) launch_bias_grad(0, dy, g.Cout, (int64_t)g.Do * g.Ho * g.Wo, db, (char*)scratch + (size_t)nb * 4 * a.total * 4 + 256, s);

@@ -554,11 +554,8 @@ static void launch_wgrad_cfg(const MfmaWgradArgs& a0, const WgradCfg& c, hipStre
     constexpr size_t red_lds = PI * PJ < 4 ? (size_t)(PI * PJ) * T * 64 * 16 : 0;   // only K-split waves reduce through LDS
     constexpr size_t lds = tile_lds > red_lds ? (tile_lds > 8192 ? tile_lds : 8192) : red_lds;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, (int)lds);
     dim3 grid((unsigned)c.nsplit, (unsigned)c.gy);
     k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ><<<grid, 256, lds, s>>>(a);
 }

@@ -1,8 +1,23 @@
 // Shared device helpers of the MFMA kernel files (gfx950).
 #pragma once
+#include <atomic>
+#include <cstdint>
+
 #include "device_util.h"
 
 namespace unet {
+
+// Dynamic-LDS opt-in of a kernel (> 64 KB needs hipFuncSetAttribute), once PER DEVICE: the C++ drop-in keeps the reference's model
+// of one process driving several devices from threads (train.cpp:592-600, other_models), and the attribute is per device.  One
+// bit per device ordinal; a racing second call sets the same value again, which is harmless.
+inline void set_max_lds_once(std::atomic<uint64_t>& done, const void* fn, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -5,6 +5,7 @@
 #include "../../include/unet_hip.h"
 
 #include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <functional>
 #include <sstream>
@@ -23,6 +24,31 @@ void* stream_of(const torch::Device& d) {
 struct Holder : torch::nn::Module {};
 
 }  // namespace
+
+// Workspace pool.  An entry = the device buffer + an event recorded on the stream of its last user when it came back; the next
+// lease makes its own stream wait for that event, so a buffer can move between host threads and streams.  At most MAX_IDLE idle
+// buffers per plan are kept (qc.cpp:263: up to 4 workers); a 128^3 bf16 workspace is ~1 GB, so "one per thread id ever seen"
+// (the first version) grew without bound under train.cpp:592-594's fresh std::threads.
+struct UNet3dImpl::WorkspacePool {
+    struct Entry { torch::Tensor buf; hipEvent_t ev = nullptr; };
+    static constexpr size_t MAX_IDLE = 4;
+    std::mutex m;
+    std::map<unet_plan*, std::vector<Entry>> idle;
+    ~WorkspacePool() { clear(); }
+    void clear() {
+        std::scoped_lock<std::mutex> lock(m);
+        for (auto& kv : idle)
+            for (auto& e : kv.second)
+                if (e.ev) (void)hipEventDestroy(e.ev);
+        idle.clear();
+    }
+    size_t count() {
+        std::scoped_lock<std::mutex> lock(m);
+        size_t n = 0;
+        for (auto& kv : idle) n += kv.second.size();
+        return n;
+    }
+};
 
 // ---- unet.cpp:103-166: constructor -------------------------------------------------------------------------
 UNet3dImpl::UNet3dImpl(int32_t in_count_, int32_t out_count_, std::string architecture_)
@@ -144,7 +170,7 @@ void UNet3dImpl::ensure_flat(void)
         std::scoped_lock<std::mutex> lock(plans_mutex_);
         for (auto& kv : plans_) unet_plan_destroy(kv.second);   // plans are bound to a device
         plans_.clear();
-        workspaces_.clear();
+        if (ws_pool_) ws_pool_->clear();
     }
     for (auto& b : buffers_)
         if (b.device() != dev) b.set_data(b.to(dev));
@@ -188,18 +214,48 @@ unet_plan* UNet3dImpl::plan_for(int64_t d, int64_t h, int64_t w)
     return p;
 }
 
-// one workspace per (plan, host thread): qc.cpp:273-297 calls forward on one model from several threads
+size_t UNet3dImpl::pooled_workspaces(void) const { return ws_pool_ ? ws_pool_->count() : 0; }
+
 torch::Tensor UNet3dImpl::workspace_for(unet_plan* plan)
 {
-    std::scoped_lock<std::mutex> lock(plans_mutex_);
-    auto key = std::make_pair(plan, std::hash<std::thread::id>()(std::this_thread::get_id()));
-    auto it = workspaces_.find(key);
-    if (it != workspaces_.end()) return it->second;
-    size_t bytes = 0;
-    unet_plan_workspace_bytes(plan, &bytes);
-    auto ws = torch::empty({(int64_t)bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(device()));
-    workspaces_[key] = ws;
-    return ws;
+    auto dev = device();
+    if (!ws_pool_) {
+        std::scoped_lock<std::mutex> lock(plans_mutex_);
+        if (!ws_pool_) ws_pool_ = std::make_shared<WorkspacePool>();
+    }
+    auto pool = ws_pool_;
+    WorkspacePool::Entry e;
+    {
+        std::scoped_lock<std::mutex> lock(pool->m);
+        auto& v = pool->idle[plan];
+        if (!v.empty()) { e = v.back(); v.pop_back(); }
+    }
+    c10::DeviceGuard guard(dev);
+    if (e.buf.defined()) {
+        if (e.ev) (void)hipStreamWaitEvent((hipStream_t)stream_of(dev), e.ev, 0);   // the previous user's kernels come first
+    } else {
+        size_t bytes = 0;
+        unet_plan_workspace_bytes(plan, &bytes);
+        e.buf = torch::empty({(int64_t)bytes}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+        if (dev.is_cuda() && hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) e.ev = nullptr;
+    }
+    // the lease aliases the pooled buffer; its deleter (run when the last reference dies: end of a no-grad forward, or the
+    // autograd node's saved data after backward / when the outputs are dropped) hands the buffer back
+    std::weak_ptr<WorkspacePool> wp = pool;
+    auto back = [wp, e, plan, dev](void*) mutable {
+        auto p = wp.lock();
+        if (e.ev && dev.is_cuda()) {
+            c10::DeviceGuard g(dev);
+            (void)hipEventRecord(e.ev, (hipStream_t)stream_of(dev));
+        }
+        if (p) {
+            std::scoped_lock<std::mutex> lock(p->m);
+            auto& v = p->idle[plan];
+            if (v.size() < WorkspacePool::MAX_IDLE) { v.push_back(e); return; }
+        }
+        if (e.ev) (void)hipEventDestroy(e.ev);   // pool gone or full: the buffer goes back to torch's allocator with `e`
+    };
+    return torch::from_blob(e.buf.data_ptr(), e.buf.sizes(), back, e.buf.options());
 }
 
 std::vector<torch::Tensor> UNet3dImpl::run_forward(unet_plan* plan, torch::Tensor ws, torch::Tensor x, int mode)

@@ -55,6 +55,11 @@ _sig("unet_plan_output_shape", _i, _vp, _i, C.POINTER(C.c_int64))
 _sig("unet_plan_workspace_bytes", _i, _vp, C.POINTER(_sz))
 _sig("unet_plan_flops", _i, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _sig("unet_plan_describe", _sz, _vp, C.c_char_p, _sz)
+_sig("unet_plan_op_count", _i, _vp, C.POINTER(_i))
+_sig("unet_plan_op_info", _i, _vp, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_int64),
+     C.POINTER(C.c_int64), C.c_char_p, _sz)
+_sig("unet_profile_begin", _i)
+_sig("unet_profile_end", _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i))
 _sig("unet_forward", _i, _vp, _pp, _pp, _vp, _pp, _vp, _i, _vp)
 _sig("unet_backward", _i, _vp, _pp, _pp, _pp, _vp, _vp, _vp)
 _sig("unet_backward_part", _i, _vp, _pp, _pp, _pp, _vp, _vp, _i, _i, _vp)
@@ -80,7 +85,7 @@ EXPORTS = [
     "unet_last_error", "unet_init", "unet_device_info", "unet_plan_create", "unet_plan_destroy", "unet_plan_param_count",
     "unet_plan_param_shape", "unet_plan_param_name", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
     "unet_plan_buffer_shape", "unet_plan_output_count", "unet_plan_output_shape", "unet_plan_workspace_bytes",
-    "unet_plan_flops", "unet_plan_describe", "unet_forward", "unet_backward", "unet_backward_part", "unet_plan_backward_buckets", "unet_loss_scratch_bytes", "unet_loss",
+    "unet_plan_flops", "unet_plan_describe", "unet_plan_op_count", "unet_plan_op_info", "unet_profile_begin", "unet_profile_end", "unet_forward", "unet_backward", "unet_backward_part", "unet_plan_backward_buckets", "unet_loss_scratch_bytes", "unet_loss",
     "unet_sgd_step", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_pack", "unet_op_conv3d_fwd_packed", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
     "unet_op_convt_fwd", "unet_op_convt_bwd_data", "unet_op_convt_bwd_weight", "unet_op_pack_ndhwc", "unet_op_unpack_ncdhw",
 ]
@@ -154,6 +159,20 @@ class Plan:
         check(lib.unet_plan_backward_buckets(self.handle, max_buckets, C.byref(n), ops, el))
         return [(ops[k], el[k]) for k in range(n.value)]
 
+    def ops(self):
+        """lowered op list: dicts with kind, cin, cout, ks, stride, in_dims, out_dims, name (unet_plan_op_info)"""
+        n = C.c_int()
+        check(lib.unet_plan_op_count(self.handle, C.byref(n)))
+        out = []
+        k, ci, co, ks, st = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        di, do = (C.c_int64 * 3)(), (C.c_int64 * 3)()
+        for i in range(n.value):
+            nm = C.create_string_buffer(128)
+            check(lib.unet_plan_op_info(self.handle, i, C.byref(k), C.byref(ci), C.byref(co), C.byref(ks), C.byref(st), di, do, nm, 128))
+            out.append({"kind": k.value, "cin": ci.value, "cout": co.value, "ks": ks.value, "stride": st.value,
+                        "in_dims": tuple(di), "out_dims": tuple(do), "name": nm.value.decode()})
+        return out
+
     def describe(self):
         n = lib.unet_plan_describe(self.handle, None, 0)
         buf = C.create_string_buffer(n)
@@ -165,3 +184,26 @@ class Plan:
         if h is not None and h.value and lib is not None:   # `lib` is None once the interpreter tears the module down
             lib.unet_plan_destroy(h)
             self.handle = C.c_void_p()
+
+
+PROF_CATEGORIES = ["conv_fwd", "dgrad", "wgrad", "norm_fwd", "norm_bwd", "other"]
+
+
+class profile:
+    """with engine.profile() as pr: ...forward/backward calls of this thread...; pr.records = [(op_index, category, ms)]"""
+
+    def __init__(self, max_records=1 << 16):
+        self.max_records, self.records = max_records, []
+
+    def __enter__(self):
+        check(lib.unet_profile_begin())
+        return self
+
+    def __exit__(self, *exc):
+        n = C.c_int()
+        op, cat, ms = (C.c_int * self.max_records)(), (C.c_int * self.max_records)(), (C.c_float * self.max_records)()
+        rc = lib.unet_profile_end(self.max_records, op, cat, ms, C.byref(n))
+        self.records = [(op[i], PROF_CATEGORIES[cat[i]], ms[i]) for i in range(n.value)]
+        if exc[0] is None:
+            check(rc)
+        return False

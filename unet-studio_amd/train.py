@@ -71,7 +71,11 @@ class Trainer:
         count = 0
         mine = list(range(self.rank, p.batch_size, self.world_size))
         works = []
-        overlap = self.world_size > 1 and self.overlap and hasattr(m, "forward_backward_bucketed")
+        # The collective sequence must be a pure function of (plan, world_size, batch_size): a rank without a sample of this step
+        # (batch_size < world_size; the reference simply starts min(gpus, batch_size) threads, train.cpp:581-582) never enters the
+        # bucketed backward, so the per-bucket all-reduces are only used when EVERY rank has at least one micro-step.
+        overlap = (self.world_size > 1 and self.overlap and hasattr(m, "forward_backward_bucketed")
+                   and p.batch_size >= self.world_size)
 
         def reduce_bucket(lo, hi):   # the bucket's gradients are final: sum them over the replicas under the rest of the backward
             if hi > lo:
@@ -88,12 +92,17 @@ class Trainer:
             count += 1
         if self.world_size > 1:
             # gradient sum over replicas (unet.cpp:224-244 -> RCCL all-reduce of the flat buffer, in buckets when overlapped)
-            if not works:
+            if not overlap:
                 dist.all_reduce(m.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self._stats, op=dist.ReduceOp.SUM, group=self.group)  # loss-stat gather, train.cpp:732-741
             for w in works:
                 w.wait()
         m.optimizer.step(grad_scale=1.0 / p.batch_size, clip_norm=12.0)  # train.cpp:759-766
+        if self.world_size > 1:
+            # bnorm running statistics: the reference overwrites every replica's buffers with the root's each step (copy_from,
+            # unet.cpp:207-215, train.cpp:573-579), so only rank 0's statistics exist -- keep it so (validate / save on any rank)
+            for b in (m.buffers() if hasattr(m, "buffers") else []):
+                dist.broadcast(b, 0, group=self.group)
         self.cur_epoch += 1
         return self._stats
 
