@@ -66,6 +66,10 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     (32, 3, (5, 6, 7), 1, 1), (16, 8, (33, 8, 9), 1, 1),
     # small-volume MFMA kernel: 8 chunks (two per wave, fragment refill), 16 chunks (two super-stages), 4^3 tile
     (256, 16, (8, 8, 8), 3, 1), (512, 32, (5, 6, 7), 3, 1), (256, 32, (4, 4, 4), 3, 1), (96, 32, (3, 4, 10), 3, 1),
+    # sliding-window MFMA wgrad (bf16, stride 1, W >= 24): every (ca-tiles, cb-tiles) pairing 1x1 / 2x1 / 1x2 / 2x2, several pair
+    # groups per launch, ragged footprints in y and x, z segments of unequal length, volumes narrower than one 32-voxel row
+    (16, 16, (9, 11, 37), 3, 1), (32, 16, (13, 9, 33), 3, 1), (16, 32, (5, 12, 40), 3, 1), (32, 32, (6, 9, 40), 3, 1),
+    (64, 32, (8, 8, 24), 3, 1), (48, 16, (4, 10, 70), 3, 1), (16, 16, (40, 8, 32), 3, 1), (32, 64, (11, 5, 29), 3, 1),
     # fp32 matrix-core conv (fp32 engine, volumes >= 4096 voxels): NT 1 / 2, ragged tile edges in z, y and x, 8-channel chunk tail
     (16, 16, (16, 16, 32), 3, 1), (32, 64, (17, 19, 21), 3, 1), (24, 48, (9, 23, 22), 3, 1), (64, 32, (18, 17, 16), 3, 1),
 ]

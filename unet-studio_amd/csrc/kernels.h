@@ -144,6 +144,14 @@ int launch_conv_first_mfma(const ConvGeom& g, const SrcDesc* src, const float* w
 // upper bound of that row count (tiles of the geometry): sizes the partials buffer
 int mfma_conv_blocks(const ConvGeom& g);
 // wgrad (+ bias grad) of a 3x3x3 conv, stride 1 or 2; dw/db fp32 torch layout, accumulated (+=); db may be nullptr
+// sliding-window wgrad of the 3x3x3 stride-1 convs (kernels_mfma_wgrad_z.hip): kernel only, returns the number of slab rows
+// written at `scratch` ([rows][Cout][Cin][27], then [rows][Cout] bias partials when want_bias); 0 = shape not covered
+bool mfma_wgrad_z_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+size_t mfma_wgrad_z_scratch_bytes(const ConvGeom& g);
+int mfma_wgrad_z_splits(const ConvGeom& g);
+int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, bool want_bias, void* scratch, hipStream_t s);
+// dw[i] += sum over rows of slab[row][i] (n % 4 == 0), db[c] += sum of bias_slab[row][c]; fixed order, no atomics
+void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, int64_t n, int Cb, float* dw, float* db, hipStream_t s);
 bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,

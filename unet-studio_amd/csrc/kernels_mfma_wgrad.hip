@@ -326,39 +326,54 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
 }
 
 // dw[i] += sum_split slab[split][i]  (slab and dw share the layout);  db[cb] += sum_split bias_slab[split][cb].
-// LX consecutive outputs x 256/LX split lanes per block: coalesced slab reads, fixed summation order.
-template <int LX>
+// A block = LX quads of 4 consecutive outputs x LY split lanes: every lane streams 16-B slab reads (8 in flight), the split
+// lanes are summed through LDS in a fixed order (bit-reproducible).  n and Cb are multiples of 4 (16-channel tiles); dw / db are
+// only 4-B aligned (a flat parameter buffer has 6-float head biases in front of later tensors), so they are updated by scalars.
+// (The first version gave each thread ONE float and nsplit/8 dependent 4-B loads: 43 us for a 14 MB slab = 0.33 TB/s.)
+template <int LX, int LY>
 __global__ void __launch_bounds__(256) k_mfma_wgrad_reduce(const float* __restrict__ slab, const float* __restrict__ bias_slab, int nsplit,
                                                            int64_t n, int Cb, float* __restrict__ dw, float* __restrict__ db) {
-    constexpr int LY = 256 / LX;
-    __shared__ double red[LY][LX];
+    static_assert(LX * LY == 256, "block shape");
+    __shared__ double red[LY > 1 ? LY : 1][LX][4];
     const int64_t ntot = n + (db && bias_slab ? Cb : 0);
     const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
-    const int64_t i = (int64_t)blockIdx.x * LX + lx;
-    double s = 0.0;
-    if (i < n) {
-        for (int k = ly; k < nsplit; k += LY) s += slab[(int64_t)k * n + i];
-    } else if (i < ntot) {
-        for (int k = ly; k < nsplit; k += LY) s += bias_slab[(int64_t)k * Cb + (i - n)];
+    const int64_t i = ((int64_t)blockIdx.x * LX + lx) * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < ntot) {
+        const float* base = i < n ? slab + i : bias_slab + (i - n);
+        const int64_t stride = i < n ? n : Cb;
+        int k = ly;
+        for (; k + 7 * LY < nsplit; k += 8 * LY) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(base + (int64_t)(k + u * LY) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+        }
+        for (; k < nsplit; k += LY) {
+            const float4 v = *(const float4*)(base + (int64_t)k * stride);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
     }
     if (LY > 1) {
-        red[ly][lx] = s;
+        red[ly][lx][0] = s0; red[ly][lx][1] = s1; red[ly][lx][2] = s2; red[ly][lx][3] = s3;
         __syncthreads();
         if (ly == 0) {
-            s = 0.0;
+            s0 = s1 = s2 = s3 = 0.0;
 #pragma unroll
-            for (int k = 0; k < LY; ++k) s += red[k][lx];
+            for (int k = 0; k < LY; ++k) { s0 += red[k][lx][0]; s1 += red[k][lx][1]; s2 += red[k][lx][2]; s3 += red[k][lx][3]; }
         }
     }
     if (ly == 0 && i < ntot) {
-        if (i < n) dw[i] += (float)s;
-        else db[i - n] += (float)s;
+        float* d = i < n ? dw + i : db + (i - n);
+        d[0] += (float)s0; d[1] += (float)s1; d[2] += (float)s2; d[3] += (float)s3;
     }
 }
-static void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, int64_t n, int Cb, float* dw, float* db, hipStream_t s) {
-    const int64_t ntot = n + (db && bias_slab ? Cb : 0);
-    if (nsplit <= 16) k_mfma_wgrad_reduce<256><<<cdiv64(ntot, 256), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
-    else k_mfma_wgrad_reduce<32><<<cdiv64(ntot, 32), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
+void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, int64_t n, int Cb, float* dw, float* db, hipStream_t s) {
+    const int64_t ntot = n + (db && bias_slab ? Cb : 0), quads = (ntot + 3) / 4;
+    if (nsplit <= 8) k_mfma_wgrad_reduce<256, 1><<<cdiv64(quads, 256), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
+    else if (nsplit <= 64) k_mfma_wgrad_reduce<64, 4><<<cdiv64(quads, 64), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
+    else k_mfma_wgrad_reduce<16, 16><<<cdiv64(quads, 16), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -537,6 +552,7 @@ static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
     return c;
 }
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g) {
+    if (size_t z = mfma_wgrad_z_scratch_bytes(g)) return z;
     WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
     return ((size_t)c.nsplit * 27 * g.Cin * g.Cout + (size_t)c.nsplit * g.Cout) * 4 + 256;
 }
@@ -575,6 +591,12 @@ static void launch_wgrad_p(const MfmaWgradArgs& a, const WgradCfg& c, hipStream_
 
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s) {
+    if (mfma_wgrad_z_supported(1, g, src, nsrc)) {   // sliding-window kernel (kernels_mfma_wgrad_z.hip): stride 1, W >= 24
+        const int ns = launch_mfma_wgrad_z(g, src, nsrc, dy, db != nullptr, scratch, s);
+        const float* slab = (const float*)scratch;
+        wgrad_reduce(slab, db ? slab + (size_t)ns * 27 * g.Cin * g.Cout : nullptr, ns, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
+        return;
+    }
     WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
     MfmaWgradArgs a;
     a.g = g; a.nasrc = nsrc; a.asrc[0] = src[0]; if (nsrc > 1) a.asrc[1] = src[1];

@@ -1,0 +1,365 @@
+// Sliding-window weight gradient of the 3x3x3 stride-1 convolutions on the matrix cores (gfx950, bf16 storage, fp32 accumulate):
+//
+//     dW[co][ci][kz][ky][kx] = sum_v  a[v + (kz-1, ky-1, kx-1)][ci] * dy[v][co]          (autograd of unet.cpp:59-72, train.cpp:706)
+//
+// 27 implicit GEMMs  D_t[ca][cb] += A_t[ca][k] * B[k][cb]  with k = voxel; both tensors are channels-last, so both MFMA operands
+// come from LDS planes [voxel][16 ch] through the transposing ds_read_b64_tr_b16 (as in k_mfma_wgrad, kernels_mfma_wgrad.hip).
+//
+// What is different from k_mfma_wgrad (halo tile per block, one A-fragment read pair PER MFMA: LDS-read bound at 1 KB per MFMA,
+// 6-12 % of the MFMA peak at 128^3):
+//   * a block owns a (BY x BX) footprint in (y, x) and WALKS z over a segment: one step stages ONE plane of the input (halo
+//     (BY+2) x (BX+2)) and ONE plane of dy, double buffered, one barrier per plane -- 1.3x the minimum LDS / L2 traffic instead of 2.8x;
+//   * a K-step is 32 voxels of a row (BX = 32) or of two rows (BX = 16).  The A fragment of (input plane p, row a, shift kx) is the
+//     operand of tap (kz, ky) for the dy rows of plane p + 1 - kz, row a - ky: with the dy fragments of the three planes p-1, p,
+//     p+1 held in REGISTERS (they rotate: each is read from LDS once), one A-fragment read pair feeds up to 9 MFMAs.  Per wave and
+//     plane: 12 A + 2 B read pairs for 54 MFMAs (0.26 KB of LDS reads per MFMA);
+//   * the 27 tap accumulators stay in registers for the whole segment; waves of a block split the rows (WK) and the
+//     (ca-tile, cb-tile) pairs (PA x PB); K-split waves are summed through LDS at the end; one slab [cb][ca][t] per block, summed
+//     in a fixed order by the reduce kernel (no float atomics: bit-reproducible).
+// Planes outside the segment / volume enter as zeros (staged zeros for the input, zero fragments for dy), so every step runs the
+// same instruction stream.
+#include <type_traits>
+
+#include "mfma_util.h"
+#ifndef WZ_RD
+#define WZ_RD 4
+#endif
+
+namespace unet {
+
+typedef __attribute__((ext_vector_type(4))) short zs16x4;
+typedef __attribute__((address_space(3))) zs16x4 zlds_s16x4;
+
+struct WgradZArgs {
+    ConvGeom g;        // Cin = Ca (input channels), Cout = Cb (dy channels); D,H,W = volume (stride 1: input = output size)
+    SrcDesc asrc[2];   // input (may be a channel concat), plain (activated copies)
+    int nasrc;
+    const void* dy;
+    float* slab;       // [gridDim.x][Cb][Ca][27]
+    float* bias_slab;  // [gridDim.x][Cb] or nullptr
+    int cols_x, cols_y, nseg, zlen;
+};
+
+__device__ __forceinline__ bf16x8 ztr_read2(const char* p0, const char* p1) {
+    zs16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((zlds_s16x4*)p0);
+    zs16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((zlds_s16x4*)p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int BX, int WK, int PA, int PB>
+__global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2) k_mfma_wgrad_z(WgradZArgs a) {
+    constexpr int NW = WK * PA * PB, NT = 64 * NW, P = PA * PB;
+    constexpr int RPK = 32 / BX;                 // rows per K-step
+    constexpr int R = 2;                         // K-steps per wave and plane
+    constexpr int BY = R * WK * RPK, HY = BY + 2, HX = BX + 2;
+    constexpr int AROW = HX * 32, APLANE = HY * AROW, BROW = BX * 32, BPLANE = BY * BROW;
+    constexpr int BUF = PA * APLANE + PB * BPLANE;
+    constexpr int T = 27;
+    constexpr int NA = RPK * (R - 1) + 3;        // A fragments (first rows) a wave reads per plane and kx
+    static_assert(BX == 32 || BX == 16, "row width");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, il = lane & 15, gq = lane >> 4;
+    const int q4 = il >> 2, p4 = il & 3;
+    const int pw = wave % P, kw = wave / P;
+    const int ia = pw / PB, ib = pw % PB;
+    const int CBG = (g.Cout / 16) / PB;                       // cb-tile groups
+    const int caB = ((int)blockIdx.y / CBG) * PA, cbB = ((int)blockIdx.y % CBG) * PB;
+    const int C0 = a.asrc[0].C;
+
+    // this block's item: footprint column and z segment (blocks that share an XCD get neighbouring items: shared halos in one L2)
+    const int item = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int seg = item % a.nseg, col = item / a.nseg;
+    const int x0 = (col % a.cols_x) * BX, y0 = (col / a.cols_x) * BY;
+    const int zs = seg * a.zlen, ze = zs + a.zlen < g.D ? zs + a.zlen : g.D, len = ze - zs;
+
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+    // ---- staging roles: a thread always stages the same (tile, 8-channel half) of A and of B ----
+    constexpr int GA = PA * 2, GB = PB * 2;
+    static_assert(NT % GA == 0 && NT % GB == 0, "fixed staging roles");
+    const int ua = tid % GA, ub = tid % GB;
+    const int ca = (caB + (ua >> 1)) * 16 + (ua & 1) * 8;
+    const int sa = (a.nasrc > 1 && ca >= C0) ? 1 : 0;
+    const int aC = sa ? a.asrc[1].C : C0;
+    const char* abase = (const char*)(sa ? a.asrc[1].ptr : a.asrc[0].ptr) + (size_t)(ca - (sa ? C0 : 0)) * 2;
+    const int cb = (cbB + (ub >> 1)) * 16 + (ub & 1) * 8;
+    const char* bbase = (const char*)a.dy + (size_t)cb * 2;
+    const bool do_bias = a.bias_slab != nullptr && caB == 0;
+    const unsigned avs = (unsigned)aC * 2, bvs = (unsigned)g.Cout * 2;
+    const size_t aplane_b = (size_t)g.H * g.W * avs, bplane_b = (size_t)g.H * g.W * bvs;
+
+    constexpr int UNITS_A = PA * HY * HX * 2, ITERS_A = (UNITS_A + NT - 1) / NT;
+    constexpr int UNITS_B = PB * BY * BX * 2, ITERS_B = (UNITS_B + NT - 1) / NT;
+    int la[ITERS_A], lb[ITERS_B];          // LDS byte offset inside a buffer (-1: no unit)
+    unsigned ga[ITERS_A], gb[ITERS_B];     // byte offset inside a plane of the source (valid units)
+    unsigned amask = 0, bmask = 0;         // unit lies inside the volume in (y, x)
+#pragma unroll
+    for (int it = 0; it < ITERS_A; ++it) {
+        const int u = tid + it * NT, hv = u / GA, hy = hv / HX, hx = hv % HX;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool in = u < UNITS_A;
+        la[it] = in ? (ua >> 1) * APLANE + hv * 32 + (ua & 1) * 16 : -1;
+        const bool ok = in && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+        if (ok) amask |= 1u << it;
+        ga[it] = ok ? (unsigned)(gy * g.W + gx) * avs : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS_B; ++it) {
+        const int u = tid + it * NT, tv = u / GB, ty = tv / BX, tx = tv % BX;
+        const int gy = y0 + ty, gx = x0 + tx;
+        const bool in = u < UNITS_B;
+        lb[it] = in ? PA * APLANE + (ub >> 1) * BPLANE + tv * 32 + (ub & 1) * 16 : -1;
+        const bool ok = in && gy < g.H && gx < g.W;
+        if (ok) bmask |= 1u << it;
+        gb[it] = ok ? (unsigned)(gy * g.W + gx) * bvs : 0u;
+    }
+    bf16x8 RA[ITERS_A], RB[ITERS_B];
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+    // input plane pz (zeros outside the volume) and dy plane bz (only asked for inside the segment)
+    auto fetch = [&](int pz, int bz, bool want_b) {
+        const bool zin = (unsigned)pz < (unsigned)g.D;
+        const char* ap = abase + (size_t)(zin ? pz : 0) * aplane_b;
+#pragma unroll
+        for (int it = 0; it < ITERS_A; ++it) {
+            bf16x8 v = zero8;
+            if (zin && ((amask >> it) & 1u)) v = *(const bf16x8*)(ap + ga[it]);
+            RA[it] = v;
+        }
+        if (want_b) {
+            const char* bp = bbase + (size_t)bz * bplane_b;
+#pragma unroll
+            for (int it = 0; it < ITERS_B; ++it) {
+                bf16x8 v = zero8;
+                if ((bmask >> it) & 1u) v = *(const bf16x8*)(bp + gb[it]);
+                RB[it] = v;
+            }
+        }
+    };
+    auto commit = [&](char* buf, bool have_b) {
+#pragma unroll
+        for (int it = 0; it < ITERS_A; ++it)
+            if ((it + 1) * NT <= UNITS_A || la[it] >= 0) *(bf16x8*)(buf + la[it]) = RA[it];
+        if (have_b) {
+#pragma unroll
+            for (int it = 0; it < ITERS_B; ++it)
+                if ((it + 1) * NT <= UNITS_B || lb[it] >= 0) {
+                    *(bf16x8*)(buf + lb[it]) = RB[it];
+                    if (do_bias) {
+                        const uint4 v = __builtin_bit_cast(uint4, RB[it]);
+                        bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+                        bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+                    }
+                }
+        }
+    };
+
+    // ---- fragment addresses: lane group gq, read r fetch voxel group G = gq + 4r of the K-step (4 consecutive x) ----
+    // row inside the K-step = G / (BX/4), x = (G % (BX/4)) * 4 + q4; lane 4q+p supplies row q (voxel q), columns 4p..4p+3
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int G = gq + 4 * r, row = G / (BX / 4), x = (G % (BX / 4)) * 4 + q4;
+        aoff[r] = ia * APLANE + ((kw * R * RPK + row) * HX + x) * 32 + p4 * 8;
+        boff[r] = PA * APLANE + ib * BPLANE + ((kw * R * RPK + row) * BX + x) * 32 + p4 * 8;
+    }
+
+    bf16x8 Bq[3][R];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < R; ++j) Bq[s][j] = zero8;
+
+    // one input plane: PH = register slot of the NEW dy plane (kz = 0); kz = 1 -> slot PH+2, kz = 2 -> slot PH+1 (mod 3)
+    auto compute = [&](auto ph, const char* buf, bool bnew) {
+        constexpr int PH = decltype(ph)::value;
+        const char* pa0 = buf + aoff[0];
+        const char* pa1 = buf + aoff[1];
+        const char* pb0 = buf + boff[0];
+        const char* pb1 = buf + boff[1];
+#pragma unroll
+        for (int j = 0; j < R; ++j) Bq[PH][j] = bnew ? ztr_read2(pb0 + j * RPK * BROW, pb1 + j * RPK * BROW) : zero8;
+        constexpr int NREAD = NA * 3, RD = WZ_RD;
+        bf16x8 ring[RD];
+#pragma unroll
+        for (int i = 0; i < RD && i < NREAD; ++i) ring[i] = ztr_read2(pa0 + ((i / 3) * HX + i % 3) * 32, pa1 + ((i / 3) * HX + i % 3) * 32);
+#pragma unroll
+        for (int i = 0; i < NREAD; ++i) {
+            const int ai = i / 3, kx = i % 3;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kz = 2; kz >= 0; --kz)                  // the new dy plane's fragments (kz = 0) are the last to be needed
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int ky = ai - RPK * j;
+                    if (ky >= 0 && ky <= 2)
+                        acc[kz * 9 + ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[i % RD], Bq[(PH + (3 - kz)) % 3][j],
+                                                                                            acc[kz * 9 + ky * 3 + kx], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + RD < NREAD) {
+                const int m = i + RD;
+                ring[m % RD] = ztr_read2(pa0 + ((m / 3) * HX + m % 3) * 32, pa1 + ((m / 3) * HX + m % 3) * 32);
+            }
+        }
+    };
+
+    // ---- the walk: step n stages input plane zs-1+n+1 and dy plane zs+n+1 while it computes input plane zs-1+n ----
+    // Three steps per loop trip, one per register slot of the new dy plane, as straight-line code: with the slot chosen by a
+    // branch inside ONE step the three inlined bodies met in phi nodes of all 27 accumulators and the allocator spilled ~150 VGPRs.
+    fetch(zs - 1, zs, len > 0);
+    commit(smem, len > 0);
+    __syncthreads();
+    auto step = [&](auto ph, int n) {
+        char* cur = smem + (n & 1) * BUF;
+        char* nxt = smem + ((n + 1) & 1) * BUF;
+        const bool more = n <= len;                       // another step follows
+        const bool nb = n + 1 < len;                      // ... and it brings a new dy plane
+        if (more) fetch(zs + n, zs + n + 1, nb);          // in flight during the MFMAs below
+        compute(ph, cur, n < len);
+        if (more) commit(nxt, nb);
+        __syncthreads();
+    };
+    for (int n = 0; n <= len + 1; n += 3) {
+        step(std::integral_constant<int, 0>{}, n);
+        if (n + 1 > len + 1) break;
+        step(std::integral_constant<int, 1>{}, n + 1);
+        if (n + 2 > len + 1) break;
+        step(std::integral_constant<int, 2>{}, n + 2);
+    }
+
+    // ---- sum the K-split waves of each pair through LDS (taps in chunks that fit), then the slab ----
+    constexpr int LDS_BYTES = 2 * BUF;
+    constexpr int TCH = (P * 27 * 1024 <= LDS_BYTES) ? 27 : ((P * 9 * 1024 <= LDS_BYTES) ? 9 : 3);
+    static_assert(P * TCH * 1024 <= LDS_BYTES, "reduction scratch");
+    float* red = (float*)smem;   // [P][TCH][64][4]
+    if constexpr (WK > 1) {
+#pragma unroll 1
+        for (int kk = 1; kk < WK; ++kk) {
+#pragma unroll
+            for (int c0 = 0; c0 < T; c0 += TCH) {
+                if (kw == kk) {
+#pragma unroll
+                    for (int t = 0; t < TCH; ++t) *(f32x4*)(red + ((pw * TCH + t) * 64 + lane) * 4) = acc[c0 + t];
+                }
+                __syncthreads();
+                if (kw == 0) {
+#pragma unroll
+                    for (int t = 0; t < TCH; ++t) {
+                        const f32x4 o = *(const f32x4*)(red + ((pw * TCH + t) * 64 + lane) * 4);
+                        acc[c0 + t][0] += o[0]; acc[c0 + t][1] += o[1]; acc[c0 + t][2] += o[2]; acc[c0 + t][3] += o[3];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // slab layout = the gradient's own layout [cb][ca][t]: a lane owns cb = il and ca = gq*4 .. +3 -> 4*T contiguous floats
+    if (kw == 0) {
+        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout +
+                    (((size_t)(cbB + ib) * 16 + il) * g.Cin + (size_t)(caB + ia) * 16 + gq * 4) * T;
+#pragma unroll
+        for (int e = 0; e < T; ++e) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = acc[(4 * e + k) % T][(4 * e + k) / T];
+            *(f32x4*)(sl + 4 * e) = v;
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        float* bred = (float*)smem;   // [NT][8]
+        static_assert(NT * 8 * 4 <= LDS_BYTES, "bias scratch");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bred[tid * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < GB * 8) {
+            const int u = tid / 8, e = tid % 8;
+            float sacc = 0.f;
+            for (int k = u; k < NT; k += GB) sacc += bred[k * 8 + e];
+            a.bias_slab[(size_t)blockIdx.x * g.Cout + (cbB + (u >> 1)) * 16 + (u & 1) * 8 + e] = sacc;
+        }
+    }
+}
+
+// ---- configuration / launch ----
+struct WgradZCfg { int bx, wk, pa, pb, by, cols_x, cols_y, nseg, zlen, gx, gy; };
+
+static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c) {
+    static const bool off = getenv("UNET_NO_WGRAD_Z") != nullptr;
+    if (off || g.ks != 3 || g.stride != 1 || g.Cin % 16 || g.Cout % 16) return false;
+    if (g.W < 24 || g.D < 4) return false;                 // narrower volumes: k_mfma_wgrad
+    const int cat = g.Cin / 16, cbt = g.Cout / 16;
+    c.bx = 32;
+    if (cat % 2 == 0 && cbt % 2 == 0) { c.pa = 2; c.pb = 2; c.wk = 2; }
+    else if (cat % 2 == 0) { c.pa = 2; c.pb = 1; c.wk = 4; }
+    else if (cbt % 2 == 0) { c.pa = 1; c.pb = 2; c.wk = 4; }
+    else { c.pa = 1; c.pb = 1; c.wk = 4; }
+    c.by = 2 * c.wk;
+    c.cols_x = (g.W + c.bx - 1) / c.bx; c.cols_y = (g.H + c.by - 1) / c.by;
+    c.gy = (cat / c.pa) * (cbt / c.pb);
+    const int cols = c.cols_x * c.cols_y;
+    const int nwaves = c.wk * c.pa * c.pb;
+    int want = (nwaves == 4 ? 512 : 256) / c.gy;           // ~8 waves per CU in total
+    if (want < 1) want = 1;
+    int nseg = (want + cols - 1) / cols;
+    if (nseg < 1) nseg = 1;
+    int zlen = (g.D + nseg - 1) / nseg;
+    if (zlen < 4) zlen = 4;                                // >= 4 planes of work per 2 warm-up steps
+    if (zlen > g.D) zlen = g.D;
+    c.nseg = (g.D + zlen - 1) / zlen; c.zlen = zlen;
+    c.gx = cols * c.nseg;
+    return true;
+}
+bool mfma_wgrad_z_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    WgradZCfg c;
+    if (dtype != 1 || !wgrad_z_cfg(g, c)) return false;
+    for (int s = 0; s < nsrc; ++s)
+        if (src[s].C % 16 || src[s].scale || src[s].act) return false;
+    return true;
+}
+int mfma_wgrad_z_splits(const ConvGeom& g) {
+    WgradZCfg c;
+    return wgrad_z_cfg(g, c) ? c.gx : 0;
+}
+size_t mfma_wgrad_z_scratch_bytes(const ConvGeom& g) {
+    WgradZCfg c;
+    if (!wgrad_z_cfg(g, c)) return 0;
+    return ((size_t)c.gx * 27 * g.Cin * g.Cout + (size_t)c.gx * g.Cout) * 4 + 256;
+}
+
+template <int BX, int WK, int PA, int PB>
+static void launch_wz(const WgradZArgs& a, const WgradZCfg& c, hipStream_t s) {
+    constexpr int RPK = 32 / BX, BY = 2 * WK * RPK, HY = BY + 2, HX = BX + 2;
+    constexpr int lds = 2 * (PA * HY * HX * 32 + PB * BY * BX * 32);
+    static_assert(lds <= 80 * 1024, "LDS budget");
+    static std::atomic<uint64_t> attr_done{0};
+    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, lds);
+    k_mfma_wgrad_z<BX, WK, PA, PB><<<dim3((unsigned)c.gx, (unsigned)c.gy), 64 * WK * PA * PB, lds, s>>>(a);
+}
+
+// Launches the kernel only: slab [gx][Cout][Cin][27] (+ bias_slab [gx][Cout] when want_bias) at `scratch`; returns the number of
+// slab rows (0: shape not covered).  The caller sums the rows (wgrad_reduce / the plan's batched reduce).
+int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, bool want_bias, void* scratch, hipStream_t s) {
+    WgradZCfg c;
+    if (!wgrad_z_cfg(g, c)) return 0;
+    WgradZArgs a;
+    a.g = g; a.nasrc = nsrc; a.asrc[0] = src[0]; if (nsrc > 1) a.asrc[1] = src[1];
+    a.dy = dy;
+    a.slab = (float*)scratch;
+    a.bias_slab = want_bias ? a.slab + (size_t)c.gx * 27 * g.Cin * g.Cout : nullptr;
+    a.cols_x = c.cols_x; a.cols_y = c.cols_y; a.nseg = c.nseg; a.zlen = c.zlen;
+    if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s);
+    else if (c.pa == 2) launch_wz<32, 4, 2, 1>(a, c, s);
+    else if (c.pb == 2) launch_wz<32, 4, 1, 2>(a, c, s);
+    else launch_wz<32, 4, 1, 1>(a, c, s);
+    return c.gx;
+}
+
+}  // namespace unet
