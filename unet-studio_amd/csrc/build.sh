@@ -12,18 +12,23 @@ for f in $SRCS; do
     o=build/${f%.*}.o
     if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then todo="$todo $f"; fi
 done
-[ -f ../conv_z_check.json ] || todo="$todo conv_z_check"
-todo_src=$(echo $todo | tr ' ' '\n' | grep -v '^conv_z_check$' | tr '\n' ' ')
+[ -f ../asm_loads_check_conv_z.json ] || todo="$todo check:kernels_mfma_conv.hip"
+[ -f ../asm_loads_check_wgrad_z.json ] || todo="$todo check:kernels_mfma_wgrad_z.hip"
+todo_src=$(echo $todo | tr ' ' '\n' | grep -v '^check:' | tr '\n' ' ')
 if [ -n "$(echo $todo_src | tr -d ' ')" ]; then
     echo $todo_src | tr ' ' '\n' | xargs -P 6 -I{} sh -c 'f={}; hipcc '"$FLAGS"' -c "$f" -o build/${f%.*}.o'
 fi
-# k_mfma_conv_z waits for inline-asm loads with hand-counted vmcnt values: check the emitted code whenever its file was rebuilt
-# (tools/check_conv_z.py: no scratch, the expected memory operations, no instruction touching a load's registers in flight)
-case " $todo " in *" kernels_mfma_conv.hip "*|*" conv_z_check "*)
-    hipcc $FLAGS --cuda-device-only -S kernels_mfma_conv.hip -o build/kernels_mfma_conv.s 2>/dev/null
-    python3 tools/check_conv_z.py build/kernels_mfma_conv.s ../conv_z_check.json || { rm -f build/kernels_mfma_conv.o; exit 1; }
-    ;;
-esac
+# k_mfma_conv_z and k_mfma_wgrad_z wait for inline-asm loads with hand-counted vmcnt values: check the emitted code whenever
+# their file was rebuilt (tools/check_asm_loads.py: no scratch, the expected memory operations, no instruction touching a load's
+# registers while it is in flight); the result and the toolchain it was validated with are recorded next to the library
+for pair in conv_z:kernels_mfma_conv wgrad_z:kernels_mfma_wgrad_z; do
+    which=${pair%%:*}; f=${pair##*:}
+    case " $todo " in *" $f.hip "*|*" check:$f.hip "*)
+        hipcc $FLAGS --cuda-device-only -S $f.hip -o build/$f.s 2>/dev/null
+        python3 tools/check_asm_loads.py $which build/$f.s ../asm_loads_check_$which.json || { rm -f build/$f.o; exit 1; }
+        ;;
+    esac
+done
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS build/${f%.*}.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../libunet_hip.so $OBJS

@@ -78,6 +78,11 @@ struct unet_plan {
     std::vector<char> dgrad_mfma;            // per op: dgrad runs on the MFMA kernel
     std::vector<char> wgrad_mfma;            // per op: wgrad runs on the MFMA kernel
     size_t wgrad_off = 0;
+    // sliding-window wgrads keep their slabs until ONE batched reduce per backward (part): per-op slab regions + the job table
+    std::vector<size_t> wz_off;              // per op: slab region (SIZE_MAX: op does not use k_mfma_wgrad_z)
+    std::vector<int> wz_job_of_op;           // per op: index into wz_jobs or -1
+    std::vector<WgradReduceJob> wz_jobs;     // ascending op index
+    WgradReduceJob* wz_jobs_dev = nullptr;
     size_t partial_off = 0, partial_bytes = 0;
     size_t ws_bytes = 0;
     // loss scratch layout
@@ -100,6 +105,7 @@ struct unet_plan {
 
     ~unet_plan() {
         if (segs_dev) (void)hipFree(segs_dev);
+        if (wz_jobs_dev) (void)hipFree(wz_jobs_dev);
         if (jobs_dev) (void)hipFree(jobs_dev);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -233,6 +239,15 @@ struct unet_plan {
         }
         wgrad_off = take(wmax ? wmax : 256);
         head_off = take(hmax ? hmax : 256);
+        wz_off.assign(g.ops.size(), SIZE_MAX);
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV || impl != UNET_IMPL_AUTO || !wgrad_mfma[i]) continue;
+            ConvGeom cg = op_geom_of(op);
+            SrcDesc sd[2];
+            for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
+            if (mfma_wgrad_z_supported(dtype, cg, sd, op.nsrc)) wz_off[i] = take(mfma_wgrad_z_scratch_bytes(cg));
+        }
         ws_bytes = off;
         // batched filter pack: one job per MFMA filter pack, sources as offsets into a flat parameter buffer
         p_off.assign(g.params.size() + 1, 0);
@@ -240,6 +255,26 @@ struct unet_plan {
             int64_t n = 1;
             for (auto d : g.params[i].shape) n *= d;
             p_off[i + 1] = p_off[i] + n;
+        }
+        wz_jobs.clear();
+        wz_job_of_op.assign(g.ops.size(), -1);
+        int wz_blk = 0;
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            if (wz_off[i] == SIZE_MAX) continue;
+            const Op& op = g.ops[i];
+            ConvGeom cg = op_geom_of(op);
+            WgradReduceJob j;
+            j.op = (int)i;
+            j.nsplit = mfma_wgrad_z_splits(cg);
+            j.n = (long long)27 * op.cin * op.cout;
+            j.Cb = op.cout;
+            j.slab_off = (long long)(wz_off[i] / 4);
+            j.bias_off = op.bias >= 0 ? j.slab_off + (long long)j.nsplit * j.n : -1;
+            j.dw_off = p_off[op.weight];
+            j.db_off = op.bias >= 0 ? p_off[op.bias] : -1;
+            wz_blk += wgrad_reduce_job_blocks(j, wz_blk);
+            wz_job_of_op[i] = (int)wz_jobs.size();
+            wz_jobs.push_back(j);
         }
         pack_jobs.clear();
         pack_blocks = 0;
@@ -478,6 +513,11 @@ struct Exec {
             HIP_OK(hipStreamWaitEvent(sb, p.ev_fork, 0));
         };
         if (op_lo < 0) op_lo = 0;
+        // gradients in one flat buffer (both hosts allocate them so): the sliding-window wgrads only write their slabs here and ONE
+        // batched reduce at the end of this call adds them all into the gradients
+        bool gflat = p.wz_jobs_dev != nullptr;
+        for (size_t k = 0; k < g.params.size() && gflat; ++k) gflat = gparams[k] == gparams[0] + p.p_off[k];
+        std::vector<char> wz_ran(p.wz_jobs.size(), 0);
         for (int i = (int)g.ops.size() - 1; i >= op_lo; --i) {
             const Op& op = g.ops[i];
             const bool dry = i >= op_hi;
@@ -520,8 +560,12 @@ struct Exec {
                         if (dry) {
                         } else if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc))
                             launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
-                        else if (p.wgrad_mfma[i])
-                            launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+                        else if (p.wgrad_mfma[i] && gflat && p.wz_job_of_op[i] >= 0) {
+                            launch_mfma_wgrad_z(cg, sd, op.nsrc, gptr(t), op.bias >= 0, ws + p.wz_off[i], sb);
+                            wz_ran[p.wz_job_of_op[i]] = 1;
+                        } else if (p.wgrad_mfma[i])
+                            launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias],
+                                                   ws + (p.wz_off[i] != SIZE_MAX ? p.wz_off[i] : p.wgrad_off), sb);
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
                             launch_wgrad_f32_mfma(cg, sd, op.nsrc, (const float*)gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
@@ -576,6 +620,16 @@ struct Exec {
                     break;
                 default: break;
             }
+        }
+        // the slabs of this call's sliding-window wgrads -> gradients: one launch per run of consecutive jobs (normally one)
+        for (size_t j = 0; j < wz_ran.size();) {
+            if (!wz_ran[j]) { ++j; continue; }
+            size_t e = j;
+            int nblk = 0;
+            while (e < wz_ran.size() && wz_ran[e]) { nblk += p.wz_jobs[e].nblk; ++e; }
+            ProfScope pr(-1, UNET_PROF_WGRAD, sb);
+            launch_wgrad_reduce_batched(p.wz_jobs_dev, (int)j, (int)(e - j), p.wz_jobs[j].blk0, nblk, ws, gparams[0], sb);
+            j = e;
         }
         if (sb != s) {   // join: whatever the caller enqueues next (optimizer step, next forward) sees every gradient
             HIP_OK(hipEventRecord(p.ev_join, sb));
@@ -663,6 +717,10 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
             HIP_OK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
             HIP_OK(hipMalloc((void**)&p->segs_dev, segs.size() * sizeof(SgdSeg)));
             HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
+            if (!p->wz_jobs.empty()) {
+                HIP_OK(hipMalloc((void**)&p->wz_jobs_dev, p->wz_jobs.size() * sizeof(WgradReduceJob)));
+                HIP_OK(hipMemcpy(p->wz_jobs_dev, p->wz_jobs.data(), p->wz_jobs.size() * sizeof(WgradReduceJob), hipMemcpyHostToDevice));
+            }
             if (!p->pack_jobs.empty()) {
                 HIP_OK(hipMalloc((void**)&p->jobs_dev, p->pack_jobs.size() * sizeof(PackJob)));
                 HIP_OK(hipMemcpy(p->jobs_dev, p->pack_jobs.data(), p->pack_jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));

@@ -152,6 +152,12 @@ int mfma_wgrad_z_splits(const ConvGeom& g);
 int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, bool want_bias, void* scratch, hipStream_t s);
 // dw[i] += sum over rows of slab[row][i] (n % 4 == 0), db[c] += sum of bias_slab[row][c]; fixed order, no atomics
 void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, int64_t n, int Cb, float* dw, float* db, hipStream_t s);
+// one launch for many layers' slabs: offsets in floats from the workspace base (slab, bias partials; bias_off < 0: none) and
+// from the flat gradient buffer (dw, db)
+struct WgradReduceJob { long long slab_off, bias_off, dw_off, db_off, n; int nsplit, Cb, ly, blk0, nblk, op; };
+int wgrad_reduce_job_blocks(WgradReduceJob& j, int blk0);
+void launch_wgrad_reduce_batched(const WgradReduceJob* jobs_dev, int job0, int njobs, int blk_base, int nblocks, const void* ws, float* gflat,
+                                 hipStream_t s);
 bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,

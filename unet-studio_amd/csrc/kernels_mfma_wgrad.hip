@@ -376,6 +376,72 @@ void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, int64_t
     else k_mfma_wgrad_reduce<16, 16><<<cdiv64(quads, 16), 256, 0, s>>>(slab, bias_slab, nsplit, n, Cb, dw, db);
 }
 
+// The same sum for MANY layers in one launch (a plan's sliding-window wgrads leave their slabs in the workspace; the backward
+// sums them once per gradient bucket instead of once per layer: ~20 dependent launches fewer per step, and the small layers'
+// reduces fill the chip together).  Offsets are in floats from the workspace base / the flat gradient buffer.
+__global__ void __launch_bounds__(256) k_wgrad_reduce_batched(const WgradReduceJob* __restrict__ jobs, int job0, int njobs, int blk_base,
+                                                              const float* __restrict__ ws, float* __restrict__ gflat) {
+    __shared__ double red[256][4];
+    __shared__ int sj;
+    if (threadIdx.x == 0) {
+        const int b = (int)blockIdx.x + blk_base;
+        int j = job0;
+        for (int k = job0; k < job0 + njobs; ++k)
+            if (b >= jobs[k].blk0) j = k;
+        sj = j;
+    }
+    __syncthreads();
+    const WgradReduceJob jb = jobs[sj];
+    const int LY = jb.ly, LX = 256 / LY;
+    const int lx = threadIdx.x % LX, ly = threadIdx.x / LX;
+    const bool hb = jb.bias_off >= 0;
+    const long long n = jb.n, ntot = n + (hb ? jb.Cb : 0);
+    const long long i = ((long long)((int)blockIdx.x + blk_base - jb.blk0) * LX + lx) * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < ntot) {
+        const float* base = i < n ? ws + jb.slab_off + i : ws + jb.bias_off + (i - n);
+        const long long stride = i < n ? n : jb.Cb;
+        int k = ly;
+        for (; k + 7 * LY < jb.nsplit; k += 8 * LY) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const float4*)(base + (long long)(k + u * LY) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+        }
+        for (; k < jb.nsplit; k += LY) {
+            const float4 v = *(const float4*)(base + (long long)k * stride);
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
+    }
+    if (LY > 1) {
+        red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2; red[threadIdx.x][3] = s3;
+        __syncthreads();
+        if (ly == 0) {
+            s0 = s1 = s2 = s3 = 0.0;
+            for (int k = 0; k < LY; ++k) { s0 += red[k * LX + lx][0]; s1 += red[k * LX + lx][1]; s2 += red[k * LX + lx][2]; s3 += red[k * LX + lx][3]; }
+        }
+    }
+    if (ly == 0 && i < ntot) {
+        float* d = i < n ? gflat + jb.dw_off + i : gflat + jb.db_off + (i - n);
+        d[0] += (float)s0; d[1] += (float)s1; d[2] += (float)s2; d[3] += (float)s3;
+    }
+}
+// fills ly / blk0 / nblk of a job (host side, plan creation); returns its block count
+int wgrad_reduce_job_blocks(WgradReduceJob& j, int blk0) {
+    j.ly = j.nsplit > 64 ? 16 : (j.nsplit > 8 ? 4 : 1);
+    const long long quads = (j.n + (j.bias_off >= 0 ? j.Cb : 0) + 3) / 4;
+    const int lx = 256 / j.ly;
+    j.blk0 = blk0;
+    j.nblk = (int)((quads + lx - 1) / lx);
+    return j.nblk;
+}
+void launch_wgrad_reduce_batched(const WgradReduceJob* jobs_dev, int job0, int njobs, int blk_base, int nblocks, const void* ws, float* gflat,
+                                 hipStream_t s) {
+    if (njobs <= 0 || nblocks <= 0) return;
+    k_wgrad_reduce_batched<<<(unsigned)nblocks, 256, 0, s>>>(jobs_dev, job0, njobs, blk_base, (const float*)ws, gflat);
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad of the network's first conv (Cin = 1, 3x3x3 stride 1, Cout = 16 * NT) on the matrix cores:
 //     D[tap][co] = sum_voxels x[voxel + tap] * dy[voxel][co]        M = 27 taps (+ row 27 = ones: the bias gradient), K = voxels

@@ -18,6 +18,7 @@
 //     in a fixed order by the reduce kernel (no float atomics: bit-reproducible).
 // Planes outside the segment / volume enter as zeros (staged zeros for the input, zero fragments for dy), so every step runs the
 // same instruction stream.
+#include <cstdio>
 #include <type_traits>
 
 #include "mfma_util.h"
@@ -120,39 +121,64 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
         if (ok) bmask |= 1u << it;
         gb[it] = ok ? (unsigned)(gy * g.W + gx) * bvs : 0u;
     }
-    bf16x8 RA[ITERS_A], RB[ITERS_B];
+    // Two register sets: the loads of plane n+2 are issued at the start of step n and stored to LDS at the end of step n+1, so two
+    // planes per block are in flight (with one set -- a single step of flight -- the kernel ran at ~3.7 TB/s: 2 blocks x 19 KB per CU
+    // do not cover HBM's latency under load).  The loads are inline assembly, waited for by hand (as in k_mfma_conv_z): left to the
+    // compiler, the zero-select of the OLDER set was hoisted to the top of the step and its vmcnt(4..0) ladder drained the set that
+    // had just been requested.  Rules that keep this safe (checked on the emitted code by tools/check_asm_loads.py at build time):
+    //   * every step issues exactly NL loads per thread and nothing else that counts in vmcnt (no stores, no compiler loads): units
+    //     outside the volume read a valid dummy address and are zeroed in LDS by a second store to the same address;
+    //   * no VALU instruction touches a prefetch register: it goes from the load straight into ds_write_b128 (both inline
+    //     assembly); the bias sums re-read the stored dy units from LDS (LDS operations of a wave execute in order).
+    constexpr int NL = ITERS_A + ITERS_B;
+    bf16x8 RA[2][ITERS_A], RB[2][ITERS_B];
     const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
-    // input plane pz (zeros outside the volume) and dy plane bz (only asked for inside the segment)
-    auto fetch = [&](int pz, int bz, bool want_b) {
+    auto fetch = [&](auto setc, int pz, int bz) {
+        constexpr int SET = decltype(setc)::value;
+        auto& ra = RA[SET];    // named here: operands of an asm statement alone do not make a generic lambda capture the arrays
+        auto& rb = RB[SET];
         const bool zin = (unsigned)pz < (unsigned)g.D;
         const char* ap = abase + (size_t)(zin ? pz : 0) * aplane_b;
 #pragma unroll
         for (int it = 0; it < ITERS_A; ++it) {
-            bf16x8 v = zero8;
-            if (zin && ((amask >> it) & 1u)) v = *(const bf16x8*)(ap + ga[it]);
-            RA[it] = v;
+            const char* ad = ap + ga[it];
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(ad) : "memory");
         }
-        if (want_b) {
-            const char* bp = bbase + (size_t)bz * bplane_b;
+        const char* bp = bbase + (size_t)((unsigned)bz < (unsigned)g.D ? bz : 0) * bplane_b;
 #pragma unroll
-            for (int it = 0; it < ITERS_B; ++it) {
-                bf16x8 v = zero8;
-                if ((bmask >> it) & 1u) v = *(const bf16x8*)(bp + gb[it]);
-                RB[it] = v;
-            }
+        for (int it = 0; it < ITERS_B; ++it) {
+            const char* ad = bp + gb[it];
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[it]) : "v"(ad) : "memory");
         }
     };
-    auto commit = [&](char* buf, bool have_b) {
+    // stores set SET: input plane pz (zeros outside the volume), dy plane only when it lies inside the segment (have_b).
+    // younger: the other set's NL loads were issued after this set's and may stay in flight.
+    auto commit = [&](auto setc, char* buf, int pz, bool have_b, bool younger) {
+        constexpr int SET = decltype(setc)::value;
+        auto& ra = RA[SET];
+        auto& rb = RB[SET];
+        const bool zin = (unsigned)pz < (unsigned)g.D;
+        if (younger) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < ITERS_A; ++it)
-            if ((it + 1) * NT <= UNITS_A || la[it] >= 0) *(bf16x8*)(buf + la[it]) = RA[it];
+            if ((it + 1) * NT <= UNITS_A || la[it] >= 0) {
+                char* d = buf + la[it];
+                const unsigned dl = (unsigned)(size_t)(__attribute__((address_space(3))) char*)d;
+                asm volatile("ds_write_b128 %0, %1" :: "v"(dl), "v"(ra[it]) : "memory");
+                if (!(zin && ((amask >> it) & 1u))) *(bf16x8*)d = zero8;
+            }
         if (have_b) {
 #pragma unroll
             for (int it = 0; it < ITERS_B; ++it)
                 if ((it + 1) * NT <= UNITS_B || lb[it] >= 0) {
-                    *(bf16x8*)(buf + lb[it]) = RB[it];
+                    char* d = buf + lb[it];
+                    const unsigned dl = (unsigned)(size_t)(__attribute__((address_space(3))) char*)d;
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(dl), "v"(rb[it]) : "memory");
+                    if (!((bmask >> it) & 1u)) *(bf16x8*)d = zero8;
                     if (do_bias) {
-                        const uint4 v = __builtin_bit_cast(uint4, RB[it]);
+                        const uint4 v = *(const uint4*)d;
                         bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
                         bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
                     }
@@ -211,28 +237,42 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
     };
 
     // ---- the walk: step n stages input plane zs-1+n+1 and dy plane zs+n+1 while it computes input plane zs-1+n ----
-    // Three steps per loop trip, one per register slot of the new dy plane, as straight-line code: with the slot chosen by a
-    // branch inside ONE step the three inlined bodies met in phi nodes of all 27 accumulators and the allocator spilled ~150 VGPRs.
-    fetch(zs - 1, zs, len > 0);
-    commit(smem, len > 0);
+    // Step n computes input plane zs-1+n from buffer n&1 (with the dy planes zs+n-2 .. zs+n in registers), stores plane zs+n
+    // (fetched during step n-1) to the other buffer and requests plane zs+n+1.  Six steps per loop trip as straight-line code:
+    // 3 register slots of the new dy plane x 2 prefetch sets are all compile-time (with the slot chosen by a branch inside ONE
+    // step body the three inlined bodies met in phi nodes of all 27 accumulators and the allocator spilled ~150 VGPRs).
+    const std::integral_constant<int, 0> c0;
+    const std::integral_constant<int, 1> c1;
+    const std::integral_constant<int, 2> c2;
+    fetch(c0, zs - 1, zs);
+    commit(c0, smem, zs - 1, len > 0, false);
+    fetch(c1, zs, zs + 1);
     __syncthreads();
-    auto step = [&](auto ph, int n) {
+    auto step = [&](auto ph, auto setc, int n) {
+        constexpr int SET = decltype(setc)::value;           // holds plane n+1 (input zs+n, dy zs+n+1); the other set is free
         char* cur = smem + (n & 1) * BUF;
         char* nxt = smem + ((n + 1) & 1) * BUF;
-        const bool more = n <= len;                       // another step follows
-        const bool nb = n + 1 < len;                      // ... and it brings a new dy plane
-        if (more) fetch(zs + n, zs + n + 1, nb);          // in flight during the MFMAs below
+        const bool more = n <= len;                          // another step follows
+        const bool ahead = n + 1 <= len;                     // plane n+2 is used by step n+2
+        if (ahead) fetch(std::integral_constant<int, 1 - SET>{}, zs + n + 1, zs + n + 2);
         compute(ph, cur, n < len);
-        if (more) commit(nxt, nb);
+        if (more) commit(setc, nxt, zs + n, n + 1 < len, ahead);
         __syncthreads();
     };
-    for (int n = 0; n <= len + 1; n += 3) {
-        step(std::integral_constant<int, 0>{}, n);
+    for (int n = 0; n <= len + 1; n += 6) {
+        step(c0, c1, n);
         if (n + 1 > len + 1) break;
-        step(std::integral_constant<int, 1>{}, n + 1);
+        step(c1, c0, n + 1);
         if (n + 2 > len + 1) break;
-        step(std::integral_constant<int, 2>{}, n + 2);
+        step(c2, c1, n + 2);
+        if (n + 3 > len + 1) break;
+        step(c0, c0, n + 3);
+        if (n + 4 > len + 1) break;
+        step(c1, c1, n + 4);
+        if (n + 5 > len + 1) break;
+        step(c2, c0, n + 5);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the epilogue reuses the prefetch registers
 
     // ---- sum the K-split waves of each pair through LDS (taps in chunks that fit), then the slab ----
     constexpr int LDS_BYTES = 2 * BUF;
@@ -306,12 +346,13 @@ static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c) {
     c.gy = (cat / c.pa) * (cbt / c.pb);
     const int cols = c.cols_x * c.cols_y;
     const int nwaves = c.wk * c.pa * c.pb;
-    int want = (nwaves == 4 ? 512 : 256) / c.gy;           // ~8 waves per CU in total
+    static const int want_env = getenv("UNET_WZ_BLOCKS") ? atoi(getenv("UNET_WZ_BLOCKS")) : 0;   // experiment knob: blocks per launch
+    int want = (want_env > 0 ? want_env : (nwaves == 4 ? 512 : 256)) / c.gy;           // ~8 waves per CU in total
     if (want < 1) want = 1;
     int nseg = (want + cols - 1) / cols;
     if (nseg < 1) nseg = 1;
     int zlen = (g.D + nseg - 1) / nseg;
-    if (zlen < 4) zlen = 4;                                // >= 4 planes of work per 2 warm-up steps
+    if (zlen < 4 && want_env <= 0) zlen = 4;               // >= 4 planes of work per 2 warm-up steps
     if (zlen > g.D) zlen = g.D;
     c.nseg = (g.D + zlen - 1) / zlen; c.zlen = zlen;
     c.gx = cols * c.nseg;
@@ -341,6 +382,13 @@ static void launch_wz(const WgradZArgs& a, const WgradZCfg& c, hipStream_t s) {
     static_assert(lds <= 80 * 1024, "LDS budget");
     static std::atomic<uint64_t> attr_done{0};
     set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, lds);
+    static const bool dbg = getenv("UNET_WZ_DEBUG") != nullptr;
+    if (dbg) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, 64 * WK * PA * PB, lds);
+        fprintf(stderr, "k_mfma_wgrad_z<%d,%d,%d,%d>: grid %d x %d, %d threads, %d B LDS, zlen %d, occupancy API: %d blocks/CU\n", BX, WK, PA, PB,
+                c.gx, c.gy, 64 * WK * PA * PB, lds, c.zlen, nb);
+    }
     k_mfma_wgrad_z<BX, WK, PA, PB><<<dim3((unsigned)c.gx, (unsigned)c.gy), 64 * WK * PA * PB, lds, s>>>(a);
 }
 

@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Post-compile gate for the kernels that wait for inline-assembly loads with hand-counted vmcnt values -- k_mfma_conv_z
+(kernels_mfma_conv.hip) and every instantiation of k_mfma_wgrad_z (kernels_mfma_wgrad_z.hip) -- run by build.sh on the device
+assembly of those files:   check_asm_loads.py conv_z <asm> <json>   |   check_asm_loads.py wgrad_z <asm> <json>
+
+What follows describes the conv_z rules; wgrad_z is checked the same way with its own expectations (per instantiation: the
+inline-asm loads come in groups of NL = loads per step, every hand-placed wait is vmcnt(NL) or vmcnt(0), no compiler-generated
+vector-memory load and no store between the first inline-asm load and the last hand-placed wait) and with the in-flight rule in
+its queue form: a hand-placed `s_waitcnt vmcnt(N)` retires all but the N youngest loads seen so far; a register is "in flight"
+from its load to that retirement, and NO instruction other than the loads themselves may read or write it meanwhile.
+
+The kernel issues its plane loads as inline assembly and waits for them with hand-counted `s_waitcnt vmcnt(3/5/7)`: hipcc neither
+counts those loads nor protects their destination registers (cdna_hip_programming.md section 5.7).  The counts are only right --
+and the registers only safe -- while the compiler adds no vector-memory operation of its own to a step and never touches a load's
+destination between the load and the ds_write that consumes it.  Nothing in the language enforces that, so this script checks
+the emitted code and fails the build when an assumption no longer holds:
+
+  1. no scratch: .vgpr_spill_count / .sgpr_spill_count / .private_segment_fixed_size are 0 and no scratch_* instruction exists
+     (a spill is a vector-memory operation the hand-placed counts do not include);
+  2. the hand-written memory operations are all there and nothing was split or duplicated: 12 inline-asm global_load_dwordx4
+     (2 prologue + 2 step instantiations x 3 units), 8 buffer_store_dwordx2 (4 plane instantiations x 2 voxels), the six
+     hand-placed waits vmcnt(3/5/7) twice each;
+  3. register safety, scanned in layout order from the first inline-asm load: a register that is the destination of an
+     inline-asm load is "in flight" until a ds_write_b128 takes it as its data operand; no other instruction may read or write
+     it while in flight (a v_mov copy, a spill, or reuse as a temporary would read or clobber data that has not landed);
+  4. the toolchain that produced this result is recorded next to the library (conv_z_check.json).
+
+UNET_NO_CONV_Z=1 (environment, read by the engine) is the documented fallback: the halo-tile kernel k_mfma_conv_p."""
+import json
+import re
+import subprocess
+import sys
+
+
+
+def regs_of(tok):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", tok):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", tok):
+        out.add(int(m.group(1)))
+    return out
+
+
+def kernel_bodies(text, match):
+    """[(symbol, lines)] of every kernel whose mangled name contains `match`"""
+    out = []
+    for m in re.finditer(r"\n(_Z[A-Za-z0-9_]*%s[A-Za-z0-9_]*):" % re.escape(match), text):
+        start = m.start()
+        end = text.find("s_endpgm", start)
+        out.append((m.group(1), text[start:end].split("\n")))
+    return out
+
+
+def metadata(text, sym):
+    meta = {}
+    for blk in text.split("  - .agpr_count:")[1:]:
+        if ("%s.kd" % sym) in blk:
+            for key in (".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size", ".vgpr_count"):
+                m = re.search(r"%s:\s+(\d+)" % re.escape(key), blk)
+                meta[key] = int(m.group(1)) if m else None
+            break
+    return meta
+
+
+def scan(body, mode):
+    """mode 'consume' (conv_z): a load's registers are in flight until a ds_write_b128 takes them as data.
+    mode 'retire' (wgrad_z): hand-placed vmcnt(N) retires all but the N youngest loads; ds_write may only read retired registers."""
+    errors, in_asm = [], False
+    asm_loads = stores = other_vmem = 0
+    waits = {}
+    queue = []          # retire mode: destination register sets in issue order
+    inflight = set()
+    seen_first = False
+    last_wait_line = max([i for i, l in enumerate(body) if "s_waitcnt vmcnt" in l] or [0])
+    for ln, line in enumerate(body):
+        t = line.strip()
+        if "#ASMSTART" in t:
+            in_asm = True
+            continue
+        if "#ASMEND" in t:
+            in_asm = False
+            continue
+        if not t or t[0] in ";." or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        op = t.split()[0]
+        args = t[len(op):]
+        if op.startswith("scratch_"):
+            errors.append("scratch instruction: %s" % t)
+        if op.startswith("buffer_store") or op.startswith("global_store"):
+            if op == "buffer_store_dwordx2":
+                stores += 1
+            if seen_first and ln < last_wait_line and (mode == "retire" or (op.startswith("buffer_store") and op != "buffer_store_dwordx2")):
+                errors.append("line %d: unexpected store between the asm loads and their waits: %s" % (ln, t))
+        if in_asm and op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                waits[n] = waits.get(n, 0) + 1
+                if mode == "retire":
+                    keep = queue[len(queue) - n:] if n else []
+                    queue = keep
+                    inflight = set().union(*keep) if keep else set()
+            continue
+        if in_asm and op == "global_load_dwordx4":
+            asm_loads += 1
+            seen_first = True
+            parts = args.split(",")
+            dst, addr = regs_of(parts[0]), regs_of(",".join(parts[1:]))
+            hit = (dst | addr) & inflight
+            if hit:
+                errors.append("line %d: load touches registers still in flight %s: %s" % (ln, sorted(hit), t))
+            inflight |= dst
+            queue.append(dst)
+            continue
+        if not in_asm and seen_first and ln < last_wait_line and (op.startswith("global_load") or op.startswith("buffer_load")) and mode == "retire":
+            other_vmem += 1
+            errors.append("line %d: compiler-generated vector load inside the hand-counted region: %s" % (ln, t))
+        used = regs_of(args)
+        if op == "ds_write_b128" and mode == "consume":
+            parts = args.split(",")
+            data = regs_of(parts[1]) if len(parts) > 1 else set()
+            if regs_of(parts[0]) & inflight:
+                errors.append("line %d: ds_write address register in flight: %s" % (ln, t))
+            inflight -= data
+            continue
+        hit = used & inflight
+        if hit:
+            errors.append("line %d: %s touches load destinations in flight %s" % (ln, t, sorted(hit)))
+    return errors, {"asm_loads": asm_loads, "buffer_store_dwordx2": stores, "hand_waits": waits}
+
+
+def main(which, path, out_json=None):
+    text = open(path).read()
+    ver = subprocess.run(["hipcc", "--version"], capture_output=True, text=True).stdout.strip().split("\n")
+    recs, failed = [], False
+    if which == "conv_z":
+        bodies = kernel_bodies(text, "k_mfma_conv_zE")
+        mode = "consume"
+    else:
+        bodies = kernel_bodies(text, "k_mfma_wgrad_zI")
+        mode = "retire"
+    if not bodies:
+        sys.exit("check_asm_loads: no %s kernel found in %s" % (which, path))
+    for sym, body in bodies:
+        meta = metadata(text, sym)
+        errors, st = scan(body, mode)
+        for key in (".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size"):
+            if meta.get(key) != 0:
+                errors.append("%s = %s (must be 0)" % (key, meta.get(key)))
+        if which == "conv_z":
+            if st["asm_loads"] != 12:
+                errors.append("inline-asm plane loads: %d (expected 12)" % st["asm_loads"])
+            if st["buffer_store_dwordx2"] != 8:
+                errors.append("buffer_store_dwordx2: %d (expected 8)" % st["buffer_store_dwordx2"])
+            if any(st["hand_waits"].get(k, 0) != 2 for k in (3, 5, 7)):
+                errors.append("hand-placed waits vmcnt(3/5/7): %s (expected 2 each)" % st["hand_waits"])
+        else:
+            # 8 fetch sites (2 prologue + 6 steps), NL loads each; 7 commit sites with a vmcnt(NL) / vmcnt(0) pair (prologue: vmcnt(0) only)
+            if st["asm_loads"] % 8:
+                errors.append("inline-asm loads: %d (expected 8 fetch sites x NL)" % st["asm_loads"])
+            nl = st["asm_loads"] // 8
+            w = st["hand_waits"]
+            if w.get(nl, 0) != 6 or w.get(0, 0) != 8 or set(w) - {0, nl}:
+                errors.append("hand-placed waits: %s (expected 6 x vmcnt(%d), 8 x vmcnt(0))" % (w, nl))
+        rec = dict(kernel=sym, ok=not errors, errors=errors, vgpr_count=meta.get(".vgpr_count"), **st)
+        recs.append(rec)
+        failed = failed or bool(errors)
+    out = {"checked": which, "ok": not failed, "kernels": recs, "validated_with": ver[:2]}
+    if out_json:
+        json.dump(out, open(out_json, "w"), indent=1)
+    if failed:
+        print("check_asm_loads: %s no longer satisfies the assumptions of its hand-placed waits:" % which, file=sys.stderr)
+        for r in recs:
+            for e in r["errors"][:12]:
+                print("   %s: %s" % (r["kernel"][-40:], e), file=sys.stderr)
+        print("   (UNET_NO_CONV_Z=1 / UNET_NO_WGRAD_Z=1 select the halo-tile kernels instead; fix the kernel or the counts before shipping)", file=sys.stderr)
+        sys.exit(1)
+    print("check_asm_loads: %s ok (%s; %s)" % (which, ", ".join("%s VGPRs / %d asm loads" % (r["vgpr_count"], r["asm_loads"]) for r in recs), ver[0] if ver else "?"))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
