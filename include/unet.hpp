@@ -45,6 +45,7 @@ inline std::ostream& operator<<(std::ostream& o, const shape3& a) { return o << 
 #endif
 
 struct unet_plan;
+struct unet_comm;
 
 struct UNet3dImpl : torch::nn::Module
 {
@@ -113,6 +114,15 @@ public: // ---- engine side (not in the reference) ----
     // fused micro-step pieces (train.cpp:634-706 and 759-766 without autograd), optional for callers
     torch::Tensor loss_and_backward(torch::Tensor input, torch::Tensor target_int64, bool ce, bool dice, bool mse, int collapse_before = 0);
     void sgd_step(float lr, float grad_scale, float clip_norm = 12.0f);
+    // Data parallel over RCCL (one process per GPU; unet_hip.h unet_comm_*).  With a communicator attached:
+    //   broadcast_parameters(0)   once at start             replaces  other_models[i]->copy_from(*model)   train.cpp:573-579
+    //   allreduce_gradients()     after the micro-steps     replaces  model->add_gradient_from(*replica)   train.cpp:756-757
+    //   loss_and_backward(..., last_micro_step = true) starts the all-reduce of every finished gradient bucket under the rest of
+    //   the backward; allreduce_gradients() then only reduces what is left and joins.  Every rank runs the same sgd_step.
+    void attach_comm(struct unet_comm* comm) { comm_ = comm; reduced_from_ = -1; }
+    void broadcast_parameters(int root = 0);
+    void allreduce_gradients(void);
+    torch::Tensor loss_and_backward_overlapped(torch::Tensor input, torch::Tensor target_int64, bool ce, bool dice, bool mse, int collapse_before = 0);
 private:
     friend struct UNetForwardFn;
     std::vector<torch::Tensor> params_, buffers_;
@@ -124,6 +134,8 @@ private:
     std::shared_ptr<WorkspacePool> ws_pool_;
     std::mutex plans_mutex_;
     torch::Tensor trigger_, momentum_, scratch_;
+    struct unet_comm* comm_ = nullptr;
+    int64_t reduced_from_ = -1;            // flat gradient elements [reduced_from_, end) are already being all-reduced (this step)
     unet_plan* plan_for(int64_t d,int64_t h,int64_t w);
     torch::Tensor workspace_for(unet_plan* plan);   // a lease: returns itself to the pool when the last reference goes away
     void bind_views(void);

@@ -40,6 +40,7 @@ extern "C" {
 typedef struct unet_plan unet_plan;
 
 const char* unet_last_error(void);
+void unet_set_error(const char* msg); /* internal: lets the library's other translation units report through unet_last_error */
 
 /* device enumeration (cuda.cu:34-74) */
 int unet_init(int* n_devices);
@@ -171,6 +172,31 @@ int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy,
 /* layout helpers: fp32 NCDHW <-> channels-last element type */
 int unet_op_pack_ndhwc(int dtype, const float* x_ncdhw, void* y_ndhwc, int C, int64_t S, void* stream);
 int unet_op_unpack_ncdhw(int dtype, const void* x_ndhwc, float* y_ncdhw, int C, int64_t S, void* stream);
+
+/* ---- gradient collectives over RCCL / xGMI ----
+ * Replaces the reference's replica synchronisation: UNet3dImpl::add_gradient_from (unet.cpp:224-244; call site train.cpp:756-757:
+ * per parameter `grad.to(device0)` + `add_` on the root) becomes ONE sum all-reduce of the flat fp32 gradient buffer (or of its
+ * finished buckets, under the rest of the backward -- unet_backward_part / unet_plan_backward_buckets), after which every rank
+ * applies the identical unet_sgd_step; the per-step weight broadcast of copy_from (unet.cpp:195-222, train.cpp:573-579) is then
+ * only needed once, at start (unet_comm_broadcast).
+ * One process per GPU: rank 0 calls unet_comm_unique_id and hands the 128 bytes to the other ranks out of band (a file, a socket,
+ * MPI, torch.distributed's store), every rank calls unet_comm_create.  One process driving several GPUs from threads (the
+ * reference's model, train.cpp:592-600): unet_comm_create_all + unet_allreduce_grads_all from one thread.
+ * Collectives are enqueued on a stream the communicator owns, ordered after `stream` (where the buffer became final) by an
+ * event; unet_comm_join makes `stream` wait for everything enqueued so far.  librccl is bound at run time (no link dependency). */
+#define UNET_COMM_ID_BYTES 128
+typedef struct unet_comm unet_comm;
+int unet_comm_unique_id(void* id_bytes /* UNET_COMM_ID_BYTES */);
+int unet_comm_create(int rank, int world, const void* id_bytes, int device, unet_comm** out);
+int unet_comm_create_all(int n, const int* devices, unet_comm** out /* n entries */);
+int unet_comm_destroy(unet_comm* comm);
+int unet_comm_rank(const unet_comm* comm, int* rank, int* world);
+/* flat[elem_lo:elem_hi] <- sum over ranks, in place (fp32) */
+int unet_allreduce_grads(unet_comm* comm, float* flat, int64_t elem_lo, int64_t elem_hi, void* stream);
+int unet_allreduce_grads_all(unet_comm* const* comms, int n, float* const* flats, int64_t elem_lo, int64_t elem_hi, void* const* streams);
+/* buf[0:n] <- root's buf (initial parameters; bnorm running statistics follow the root like copy_from's buffers, unet.cpp:207-215) */
+int unet_comm_broadcast(unet_comm* comm, float* buf, int64_t n, int root, void* stream);
+int unet_comm_join(unet_comm* comm, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 // with the same torch::nn modules, in the same order, as the reference's unet.cpp:24-193 builds for this DSL string.
 // Exit code 0 and "OK" on success.  Usage: test_unet_hpp [fp32|bf16]
 #include "unet.hpp"
+#include "unet_hip.h"
 #include <c10/hip/HIPCachingAllocator.h>
 #include <atomic>
 #include <iostream>
@@ -157,6 +158,34 @@ int main(int argc, char** argv) {
         REQUIRE(failures == 0, "concurrent eval forward threw");
         for (int k = 0; k < 4; ++k) REQUIRE(got[k].defined() && torch::equal(got[k], serial), "concurrent eval forward " + std::to_string(k) + " differs");
         REQUIRE(model->pooled_workspaces() <= 4, "pool exceeds its bound");
+    }
+    // ---- RCCL under the C ABI, driven from the C++ host: a one-rank communicator must leave the step unchanged ----
+    {
+        char id[UNET_COMM_ID_BYTES];
+        unet_comm* comm = nullptr;
+        REQUIRE(unet_comm_unique_id(id) == 0, std::string("unet_comm_unique_id: ") + unet_last_error());
+        REQUIRE(unet_comm_create(0, 1, id, 0, &comm) == 0, std::string("unet_comm_create: ") + unet_last_error());
+        UNet3d a(1, 3, arch), b(1, 3, arch);
+        a->engine_dtype = b->engine_dtype = model->engine_dtype;
+        a->to(dev); b->to(dev);
+        b->copy_from(*a);
+        a->train(); b->train();
+        b->attach_comm(comm);
+        b->broadcast_parameters(0);
+        auto xd = x.to(dev);
+        auto tgt = torch::randint(0, 3, {1, 12, 16, 20}, torch::TensorOptions().dtype(torch::kLong).device(dev));
+        for (int stp = 0; stp < 2; ++stp) {
+            auto la = a->loss_and_backward(xd, tgt, true, true, true);
+            a->sgd_step(0.01f, 1.0f);
+            auto lb = b->loss_and_backward_overlapped(xd, tgt, true, true, true);     // bucketed backward + asynchronous all-reduces
+            b->allreduce_gradients();                                                // the rest + join (train.cpp:756-757)
+            b->sgd_step(0.01f, 1.0f);
+            REQUIRE(torch::equal(la, lb), "losses with a one-rank communicator");
+        }
+        torch::cuda::synchronize();
+        REQUIRE(torch::equal(a->flat_params, b->flat_params), "parameters with a one-rank communicator differ from the no-collective run");
+        b->attach_comm(nullptr);
+        REQUIRE(unet_comm_destroy(comm) == 0, "unet_comm_destroy");
     }
     std::cout << model->get_info();
     std::cout << "OK " << (bf16 ? "bf16" : "fp32") << " logits rel " << rel(outs[0], yr) << std::endl;

@@ -124,3 +124,23 @@ def test_configs3_workload_two_ranks_default_arch_128_bf16():
     assert float(np.abs(du - dr).max()) <= 2e-2 * float(np.abs(dr).max()) + 1e-9
     assert np.allclose(s0, sref, rtol=2e-3, atol=1e-4)
     assert np.allclose(s0, s1)
+
+
+def test_one_rank_rccl_communicator_under_the_c_abi_leaves_the_step_unchanged():
+    """unet_comm_* (include/unet_hip.h): the trainer's collectives through RCCL under the C ABI -- per-bucket unet_allreduce_grads
+    on the communicator's stream under the bucketed backward, the loss-statistics sum, unet_comm_join before the update.  With one
+    rank every sum is the identity, so parameters and statistics must be bit-identical to the trainer without any collective."""
+    import unet_studio_amd as U
+
+    def run(use_comm):
+        m = U.UNet3d(1, 4, ARCH, device="cuda:0", dtype="bf16", seed=0)
+        src = U.SyntheticVolumes(1, 4, (N, N, N), "cuda:0", cache=8)
+        comm = U.engine.Comm.single(0) if use_comm else None
+        tr = U.Trainer(m, U.TrainingParam(batch_size=2, epoch=100, learning_rate=0.05), lambda i: src(i % 8), comm=comm)
+        stats = [tr.step().clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        return m.flat_params.clone(), torch.stack(stats)
+
+    p0, s0 = run(False)
+    p1, s1 = run(True)
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)

@@ -3,7 +3,7 @@
 # Objects are compiled in parallel (one hipcc per source) and only when the source or a header is newer.
 set -e
 cd "$(dirname "$0")"
-SRCS="graph.cpp engine.cpp kernels_direct.hip kernels_elem.hip kernels_mfma_conv.hip kernels_mfma_wgrad.hip kernels_mfma_wgrad_z.hip kernels_augment.hip kernels_mfma_f32.hip"
+SRCS="graph.cpp engine.cpp comm.cpp kernels_direct.hip kernels_elem.hip kernels_mfma_conv.hip kernels_mfma_wgrad.hip kernels_mfma_wgrad_z.hip kernels_augment.hip kernels_mfma_f32.hip"
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-result"
 mkdir -p build
 newest_hdr=$(ls -t *.h *.hpp ../../include/*.h | head -1)
@@ -31,5 +31,5 @@ for pair in conv_z:kernels_mfma_conv wgrad_z:kernels_mfma_wgrad_z; do
 done
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS build/${f%.*}.o"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libunet_hip.so $OBJS
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libunet_hip.so $OBJS -ldl
 echo "built $(cd .. && pwd)/libunet_hip.so"

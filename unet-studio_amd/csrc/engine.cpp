@@ -648,6 +648,7 @@ void check_launch() { HIP_OK(hipGetLastError()); }
 extern "C" {
 
 const char* unet_last_error(void) { return g_err.c_str(); }
+void unet_set_error(const char* msg) { g_err = msg ? msg : ""; }   // comm.cpp reports through the same thread-local message
 
 int unet_init(int* n_devices) {
     int n = 0;

@@ -444,6 +444,77 @@ torch::Tensor UNet3dImpl::loss_and_backward(torch::Tensor input, torch::Tensor t
     return losses;
 }
 
+// ---- data parallel over RCCL: the C++ host's replacement of train.cpp:573-579 (copy_from per step) and :756-757 (add_gradient_from) ----
+void UNet3dImpl::broadcast_parameters(int root)
+{
+    if (!comm_) throw std::runtime_error("broadcast_parameters: no communicator attached");
+    ensure_flat();
+    void* st = stream_of(flat_params.device());
+    check(unet_comm_broadcast(comm_, flat_params.data_ptr<float>(), flat_params.numel(), root, st));
+    for (auto& b : buffers_) check(unet_comm_broadcast(comm_, b.data_ptr<float>(), b.numel(), root, st));   // unet.cpp:207-215
+    check(unet_comm_join(comm_, st));
+}
+
+void UNet3dImpl::allreduce_gradients(void)
+{
+    if (!comm_) throw std::runtime_error("allreduce_gradients: no communicator attached");
+    ensure_flat();
+    rebind_grads();
+    void* st = stream_of(flat_grads.device());
+    const int64_t hi = reduced_from_ >= 0 ? reduced_from_ : flat_grads.numel();   // buckets above were started by the overlapped backward
+    check(unet_allreduce_grads(comm_, flat_grads.data_ptr<float>(), 0, hi, st));
+    check(unet_comm_join(comm_, st));
+    reduced_from_ = -1;
+}
+
+// loss_and_backward for a rank's LAST micro-step of an optimizer step: the backward runs in buckets (unet_plan_backward_buckets) and the
+// all-reduce of each finished bucket starts at once on the communicator's stream; the last bucket is left to allreduce_gradients()
+torch::Tensor UNet3dImpl::loss_and_backward_overlapped(torch::Tensor input, torch::Tensor target, bool ce, bool dice, bool mse, int collapse_before)
+{
+    if (!comm_) return loss_and_backward(input, target, ce, dice, mse, collapse_before);
+    ensure_flat();
+    rebind_grads();
+    auto x = input.to(torch::kFloat32).contiguous();
+    unet_plan* plan = plan_for(x.size(2), x.size(3), x.size(4));
+    auto ws = workspace_for(plan);
+    auto outs = run_forward(plan, ws, x, 1);
+    size_t sb = 0;
+    unet_loss_scratch_bytes(plan, &sb);
+    auto sc = torch::empty({(int64_t)sb}, torch::TensorOptions().dtype(torch::kUInt8).device(x.device()));
+    auto losses = torch::empty({4}, torch::TensorOptions().dtype(torch::kFloat32).device(x.device()));
+    std::vector<torch::Tensor> gouts;
+    std::vector<const float*> op, go;
+    std::vector<float*> gp;
+    for (auto& o : outs) {
+        gouts.push_back(o.defined() ? torch::empty_like(o) : torch::Tensor());
+        op.push_back(o.defined() ? o.data_ptr<float>() : nullptr);
+        gp.push_back(o.defined() ? gouts.back().data_ptr<float>() : nullptr);
+        go.push_back(gp.back());
+    }
+    auto t = target.to(torch::kLong).contiguous();
+    int mask = (ce ? 1 : 0) | (dice ? 2 : 0) | (mse ? 4 : 0);
+    void* st = stream_of(x.device());
+    check(unet_loss(plan, op.data(), t.data_ptr<int64_t>(), mask, collapse_before, gp.data(), losses.data_ptr<float>(), sc.data_ptr(), st));
+    std::vector<const float*> pp;
+    std::vector<float*> gw;
+    int64_t off = 0;
+    for (auto& p : params_) { pp.push_back(p.data_ptr<float>()); gw.push_back(flat_grads.data_ptr<float>() + off); off += p.numel(); }
+    int nb = 0, op_lo[8];
+    int64_t elem_lo[8];
+    check(unet_plan_backward_buckets(plan, 3, &nb, op_lo, elem_lo));
+    int op_hi = 1 << 30;
+    int64_t elem_hi = flat_grads.numel();
+    for (int k = 0; k < nb; ++k) {
+        check(unet_backward_part(plan, pp.data(), go.data(), gw.data(), nullptr, ws.data_ptr(), op_hi, op_lo[k], st));
+        if (k + 1 < nb) {   // finished bucket: its sum over the ranks runs under the next part of the backward
+            check(unet_allreduce_grads(comm_, flat_grads.data_ptr<float>(), elem_lo[k], elem_hi, st));
+            reduced_from_ = elem_lo[k];
+        }
+        op_hi = op_lo[k]; elem_hi = elem_lo[k];
+    }
+    return losses;
+}
+
 void UNet3dImpl::sgd_step(float lr, float grad_scale, float clip_norm)
 {
     ensure_flat();

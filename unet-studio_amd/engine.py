@@ -67,6 +67,16 @@ _sig("unet_plan_backward_buckets", _i, _vp, _i, C.POINTER(_i), C.POINTER(_i), C.
 _sig("unet_loss_scratch_bytes", _i, _vp, C.POINTER(_sz))
 _sig("unet_loss", _i, _vp, _pp, _vp, _i, _i, _pp, _vp, _vp, _vp)
 _sig("unet_sgd_step", _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _f, _vp, _vp, _vp)
+_sig("unet_set_error", None, C.c_char_p)
+_sig("unet_comm_unique_id", _i, _vp)
+_sig("unet_comm_create", _i, _i, _i, _vp, _i, C.POINTER(_vp))
+_sig("unet_comm_create_all", _i, _i, C.POINTER(_i), C.POINTER(_vp))
+_sig("unet_comm_destroy", _i, _vp)
+_sig("unet_comm_rank", _i, _vp, C.POINTER(_i), C.POINTER(_i))
+_sig("unet_allreduce_grads", _i, _vp, _vp, C.c_int64, C.c_int64, _vp)
+_sig("unet_allreduce_grads_all", _i, _pp, _i, _pp, C.c_int64, C.c_int64, _pp)
+_sig("unet_comm_broadcast", _i, _vp, _vp, C.c_int64, _i, _vp)
+_sig("unet_comm_join", _i, _vp, _vp)
 _sig("unet_op_scratch_bytes", _i, _i, _i, _i, _i, _i, C.POINTER(_sz))
 _sig("unet_op_conv3d_fwd", _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp)
 _sig("unet_op_conv3d_pack", _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp)
@@ -86,7 +96,8 @@ EXPORTS = [
     "unet_plan_param_shape", "unet_plan_param_name", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
     "unet_plan_buffer_shape", "unet_plan_output_count", "unet_plan_output_shape", "unet_plan_workspace_bytes",
     "unet_plan_flops", "unet_plan_describe", "unet_plan_op_count", "unet_plan_op_info", "unet_profile_begin", "unet_profile_end", "unet_forward", "unet_backward", "unet_backward_part", "unet_plan_backward_buckets", "unet_loss_scratch_bytes", "unet_loss",
-    "unet_sgd_step", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_pack", "unet_op_conv3d_fwd_packed", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
+    "unet_sgd_step", "unet_set_error", "unet_comm_unique_id", "unet_comm_create", "unet_comm_create_all", "unet_comm_destroy", "unet_comm_rank",
+    "unet_allreduce_grads", "unet_allreduce_grads_all", "unet_comm_broadcast", "unet_comm_join", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_pack", "unet_op_conv3d_fwd_packed", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
     "unet_op_convt_fwd", "unet_op_convt_bwd_data", "unet_op_convt_bwd_weight", "unet_op_pack_ndhwc", "unet_op_unpack_ncdhw",
 ]
 
@@ -207,3 +218,51 @@ class profile:
         if exc[0] is None:
             check(rc)
         return False
+
+
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """unet_comm: RCCL communicator under the C ABI (one process per GPU).  The 128-byte id is made on rank 0 and handed to the
+    other ranks out of band; `from_torch_distributed` uses an existing process group (any backend) as that side channel only."""
+
+    def __init__(self, rank, world, id_bytes, device=0):
+        self.handle = C.c_void_p()
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        check(lib.unet_comm_create(rank, world, buf, device, C.byref(self.handle)))
+        self.rank, self.world, self.device = rank, world, device
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * COMM_ID_BYTES)()
+        check(lib.unet_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def single(cls, device=0):
+        return cls(0, 1, cls.unique_id(), device)
+
+    @classmethod
+    def from_torch_distributed(cls, device, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(rank, world, box[0], device)
+
+    def allreduce(self, flat, lo, hi, stream):
+        """flat[lo:hi] (fp32, device) <- sum over ranks; enqueued after `stream`'s work so far, on the communicator's own stream"""
+        check(lib.unet_allreduce_grads(self.handle, flat.data_ptr(), int(lo), int(hi), stream))
+
+    def broadcast(self, buf, root, stream):
+        check(lib.unet_comm_broadcast(self.handle, buf.data_ptr(), int(buf.numel()), int(root), stream))
+
+    def join(self, stream):
+        check(lib.unet_comm_join(self.handle, stream))
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h is not None and h.value and lib is not None:
+            lib.unet_comm_destroy(h)
+            self.handle = C.c_void_p()

@@ -46,9 +46,13 @@ class SyntheticVolumes:
 class Trainer:
     """train_unet's thread C (train.cpp:554-805) for one rank."""
 
-    def __init__(self, model, param, source, rank=0, world_size=1, group=None):
+    def __init__(self, model, param, source, rank=0, world_size=1, group=None, comm=None):
+        """comm: an engine.Comm (RCCL under the C ABI, include/unet_hip.h unet_comm_*): the gradient / statistics collectives then
+        go through unet_allreduce_grads instead of torch.distributed -- the same calls the C++ host makes (unet_host.cpp)."""
         self.model, self.param, self.source = model, param, source
-        self.rank, self.world_size, self.group = rank, world_size, group
+        self.rank, self.world_size, self.group, self.comm = rank, world_size, group, comm
+        if comm is not None:
+            self.rank, self.world_size = comm.rank, comm.world
         # world_size > 1: start the all-reduce of every finished gradient bucket under the rest of the backward
         self.overlap = os.environ.get("UNET_NO_OVERLAP") is None
         self.cur_epoch = 0
@@ -74,11 +78,14 @@ class Trainer:
         # The collective sequence must be a pure function of (plan, world_size, batch_size): a rank without a sample of this step
         # (batch_size < world_size; the reference simply starts min(gpus, batch_size) threads, train.cpp:581-582) never enters the
         # bucketed backward, so the per-bucket all-reduces are only used when EVERY rank has at least one micro-step.
-        overlap = (self.world_size > 1 and self.overlap and hasattr(m, "forward_backward_bucketed")
-                   and p.batch_size >= self.world_size)
+        multi = self.world_size > 1 or self.comm is not None
+        overlap = (multi and self.overlap and hasattr(m, "forward_backward_bucketed") and p.batch_size >= self.world_size)
+        stream = torch.cuda.current_stream(m.device()).cuda_stream if self.comm is not None else None
 
         def reduce_bucket(lo, hi):   # the bucket's gradients are final: sum them over the replicas under the rest of the backward
-            if hi > lo:
+            if hi > lo and self.comm is not None:
+                self.comm.allreduce(m.flat_grads, lo, hi, stream)     # on the communicator's stream, after the bucket's kernels
+            elif hi > lo:
                 works.append(dist.all_reduce(m.flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
         for k, b in enumerate(mine):
@@ -90,7 +97,12 @@ class Trainer:
                 losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse)
             self._stats += losses
             count += 1
-        if self.world_size > 1:
+        if self.comm is not None:
+            if not overlap:
+                self.comm.allreduce(m.flat_grads, 0, m.flat_grads.numel(), stream)
+            self.comm.allreduce(self._stats, 0, 4, stream)          # loss-stat gather, train.cpp:732-741
+            self.comm.join(stream)                                  # the update below reads the summed gradients
+        elif self.world_size > 1:
             # gradient sum over replicas (unet.cpp:224-244 -> RCCL all-reduce of the flat buffer, in buckets when overlapped)
             if not overlap:
                 dist.all_reduce(m.flat_grads, op=dist.ReduceOp.SUM, group=self.group)
@@ -98,7 +110,11 @@ class Trainer:
             for w in works:
                 w.wait()
         m.optimizer.step(grad_scale=1.0 / p.batch_size, clip_norm=12.0)  # train.cpp:759-766
-        if self.world_size > 1:
+        if self.comm is not None and self.world_size > 1:
+            for b in m.buffers():
+                self.comm.broadcast(b, 0, stream)
+            self.comm.join(stream)
+        elif self.world_size > 1:
             # bnorm running statistics: the reference overwrites every replica's buffers with the root's each step (copy_from,
             # unet.cpp:207-215, train.cpp:573-579), so only rank 0's statistics exist -- keep it so (validate / save on any rank)
             for b in (m.buffers() if hasattr(m, "buffers") else []):
