@@ -146,5 +146,10 @@ private:
 };
 TORCH_MODULE_IMPL(UNet3d, UNet3dImpl);
 
+// `.nz` network files (the reference declares these in train.hpp:32-33 and defines them in main.cpp:157-233 over TIPL's gz_mat
+// container; here: unet-studio_amd/csrc/nz_io.cpp, gzip + MATLAB Level-4 records, plain float tensors)
+bool save_to_file(UNet3d& model,const char* file_name);
+bool load_from_file(UNet3d& model,const char* file_name);
+
 
 #endif// UNET_HPP

@@ -609,3 +609,20 @@ def test_evaluate_loop_matches_the_reference_inference(dt):
     # an input the network cannot take ends the run the reference's way: message + aborted, no exception (evaluate.cpp:234-242)
     bad = ev.start([[np.zeros((2 * 5, 24, 32), np.float32)]])
     assert ev.aborted and ev.error_msg.startswith("error during evaluation:") and ev.cur_prog == 0
+
+
+def test_nz_file_round_trip_through_the_engine(tmp_path):
+    """save_to_file / load_from_file (main.cpp:157-233) around a real model: the reloaded network gives the same logits, and the
+    checkpoint written every 100 steps (train.cpp:780-788) carries the error history."""
+    arch = ("conv8,ks3,stride1+norm,leaky_relu\nconv16,ks3,stride2+norm,leaky_relu+conv_trans8,ks2,stride2\n"
+            "conv8,ks3,stride1+norm,leaky_relu+conv3,ks1,stride1")
+    m = U.UNet3d(1, 3, arch, device=DEV, dtype="fp32", seed=3)
+    m.training_errors, m.testing_errors = [0.3, 0.2, 0.1], [0.4, 0.3, 0.2]
+    m.voxel_size, m.dim = (0.5, 0.5, 2.0), (64, 96, 32)
+    f = str(tmp_path / "model.nz")
+    assert U.save_to_file(m, f)
+    r = U.load_from_file(f, device=DEV, dtype="fp32")
+    assert r.architecture == m.architecture and r.dim == m.dim and r.testing_errors == pytest.approx(m.testing_errors)
+    x, _ = U.SyntheticVolumes(1, 3, (16, 16, 16), DEV)(0)
+    m.eval(); r.eval()
+    assert torch.equal(m.forward(x)[0], r.forward(x)[0])

@@ -10,6 +10,19 @@ from .train import SyntheticVolumes, Trainer, TrainingParam  # noqa: F401
 from . import augment  # noqa: F401
 from .evaluate import EvaluateUNet  # noqa: F401
 from .augment import AugmentedVolumes, visual_perception_augmentation  # noqa: F401
+from . import nz  # noqa: F401
+from .nz import NzError  # noqa: F401
+
+
+def save_to_file(model, file_name):
+    """bool save_to_file(UNet3d& model, const char* file_name) -- main.cpp:207-233 (`.nz`: gzip + MATLAB Level-4 records, nz.py)"""
+    return nz.save_to_file(model, file_name)
+
+
+def load_from_file(file_name, device="cuda:0", dtype="bf16"):
+    """load_from_file (main.cpp:157-206): builds UNet3d(channels[0], channels[1], architecture) on `device` and fills
+    parameters() from tensor0..N; raises NzError with the reference's messages."""
+    return nz.load_from_file(file_name, lambda i, o, a: UNet3d(i, o, a, device=device, dtype=dtype))
 
 
 def default_feature(out_count):
