@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+# UNET_HIP_LIBRARY: another build of the SAME library (csrc/tools/sanitize_host.sh: host code under ASan/UBSan); never a fallback
+LIB_PATH = os.environ.get("UNET_HIP_LIBRARY") or os.path.join(_HERE, "libunet_hip.so")
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 IMPL_AUTO, IMPL_DIRECT = 0, 1
