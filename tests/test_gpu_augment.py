@@ -176,6 +176,33 @@ def test_augmented_source_feeds_a_train_step():
     assert torch.isfinite(s).all()
 
 
+def test_sample_ring_hands_over_the_synchronous_samples():
+    """PrefetchedVolumes (the device-resident form of the reader ring, train.cpp:259-486): sample i+1 is produced on a side stream
+    while step i trains.  The samples, and therefore the trained parameters, are the synchronous source's bit for bit."""
+    arch = ("conv8,ks3,stride1+norm,leaky_relu\nconv16,ks3,stride2+norm,leaky_relu+conv_trans8,ks2,stride2\n"
+            "conv8,ks3,stride1+norm,leaky_relu+conv4,ks1,stride1")
+    base = U.SyntheticVolumes(2, 4, (16, 24, 32), DEV, cache=4)
+    direct = U.AugmentedVolumes(lambda i: base(i % 4))
+    ring = U.PrefetchedVolumes(U.AugmentedVolumes(lambda i: base(i % 4)), stride=1)
+    for i in (0, 1, 2, 5, 6):                        # consecutive requests are prefetched, a jump is produced on demand
+        xa, ta = direct(i)
+        xb, tb = ring(i)
+        torch.cuda.synchronize()
+        assert torch.equal(xa, xb) and torch.equal(ta, tb), i
+
+    def run(feed):
+        m = U.UNet3d(2, 4, arch, device=DEV, dtype="bf16", seed=0)
+        tr = U.Trainer(m, U.TrainingParam(batch_size=2, epoch=10, learning_rate=0.01), feed)
+        for _ in range(4):
+            tr.step()
+        torch.cuda.synchronize()
+        return m.flat_params.clone()
+
+    pa = run(U.AugmentedVolumes(lambda i: base(i % 4)))
+    pb = run(U.PrefetchedVolumes(U.AugmentedVolumes(lambda i: base(i % 4)), stride=1))
+    assert torch.equal(pa, pb)
+
+
 # ---- simulate_modality (train.cpp:43-178) ----
 @pytest.mark.parametrize("seed", [0, 1, 2])
 @pytest.mark.parametrize("with_label", [True, False])

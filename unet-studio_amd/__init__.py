@@ -9,7 +9,7 @@ from .unet3d import SGD, UNet3d  # noqa: F401
 from .train import SyntheticVolumes, Trainer, TrainingParam  # noqa: F401
 from . import augment  # noqa: F401
 from .evaluate import EvaluateUNet  # noqa: F401
-from .augment import AugmentedVolumes, visual_perception_augmentation  # noqa: F401
+from .augment import AugmentedVolumes, PrefetchedVolumes, visual_perception_augmentation  # noqa: F401
 from . import nz  # noqa: F401
 from .nz import NzError  # noqa: F401
 

@@ -288,6 +288,43 @@ class AugmentedVolumes:
         return x, lab.to(torch.int64)[None]
 
 
+class PrefetchedVolumes:
+    """Device-resident sample ring: the role of the reader / augmentation threads' `file_ready / data_ready` ring
+    (train.cpp:259-486: samples are produced ahead of the trainer, which only waits on a flag) on ONE GPU -- sample i + stride is
+    produced (template -> augmentation / simulate_modality kernels) on a side stream into buffers of its own while the training
+    stream runs step i, and `__call__(i)` hands over the sample prepared earlier after making the training stream wait for its
+    event.  `stride` = how far apart this rank's consecutive requests are (world_size when ranks take every world-th sample).
+    Results are the synchronous source's bit for bit: the recipe is a function of the sample index alone."""
+
+    def __init__(self, source, stride=1, device=None):
+        import torch
+        self.source, self.stride = source, int(stride)
+        self.stream = torch.cuda.Stream(device=device, priority=0)
+        self._ready = {}
+
+    def _produce(self, index):
+        import torch
+        self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))   # the templates the source reads are final
+        with torch.cuda.stream(self.stream):
+            x, t = self.source(index)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._ready[index] = (x, t, ev)
+
+    def __call__(self, index):
+        import torch
+        if index not in self._ready:
+            self._produce(index)                     # first request (or a jump): produced now, still off the training stream
+        x, t, ev = self._ready.pop(index)
+        cur = torch.cuda.current_stream(x.device)
+        cur.wait_event(ev)
+        x.record_stream(cur)                         # allocated on the side stream, consumed on the training stream
+        t.record_stream(cur)
+        if len(self._ready) < 2:
+            self._produce(index + self.stride)       # runs beside the step that consumes `index`
+        return x, t
+
+
 # ---- simulate_modality (train.cpp:43-178) --------------------------------------------------------------------------------
 SIM_TERMS, SIM_MAX_LABELS = 20, 256
 
