@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event profile (roofline / conv_mfma_frac)")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the single-kernel micro-benchmarks (roofline_kernels)")
     # BASELINE.json configs[4] (not the headline line): --size 256 --in-channels 2 --augment --no-cpu-baseline
     ap.add_argument("--in-channels", type=int, default=1)
     ap.add_argument("--augment", action="store_true", help="augment every sample on the GPU inside the timed step (unet_augment_run)")
@@ -349,7 +350,7 @@ def main():
                                              "HIP events around it inside %d profiled steps"
                                              % (d["pass"], d["op"], d["shape"], 100.0 * d["share_of_conv_time"], prof["profiled_steps"]),
                                    "avg_launch_ms": d["ms"]}
-        if n == 128 and cin == 1:
+        if n == 128 and cin == 1 and not a.no_kernels:
             kflops, ksec = dominant_kernel(U, n, a.dtype)
             tr_b, tr_src = recorded_traffic("dominant_kernel_traffic") if a.dtype == "bf16" else (None, None)
             kernels.append({"kernel": "conv3d fwd 32->16 3x3x3 @%d^3 (decode0.0, 23.7%% of forward FLOPs), unet_op_conv3d_fwd_packed" % n,

@@ -6,7 +6,7 @@ export TMPDIR=/tmp UNET_NO_SIDE_STREAM=1
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $R/gpurun_out/step_$c
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/step_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $R/gpurun_out/step_$c.log 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/step_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile --no-kernels > $R/gpurun_out/step_$c.log 2>&1
 done
 python3 - "$R" <<'PY'
 import csv, glob, sys, collections, re
@@ -14,13 +14,13 @@ R = sys.argv[1]
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.Counter(); n = collections.Counter()
-    for f in glob.glob("%s/gpurun_out/step_%s/*/*counter_collection.csv" % (R, c)):
+    for f in glob.glob("%s/gpurun_out/step_%s/*/*counter_collection.csv" % (R, c)) + glob.glob("%s/gpurun_out/step_%s/*counter_collection.csv" % (R, c)):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c: continue
             k = re.sub(r"<.*", "", r["Kernel_Name"]).replace("void ", "").replace("unet::", "")
             acc[k] += float(r["Counter_Value"]); n[k] += 1
     tot[c] = (acc, n)
-steps = 5.0   # 4 timed + 1 warm-up (the dominant-kernel microbench launches are in there too)
+steps = 5.0   # 4 timed + 1 warm-up (no profile pass, no micro-benchmarks: --no-profile --no-kernels)
 keys = set(tot["FETCH_SIZE"][0]) | set(tot["WRITE_SIZE"][0])
 rows = []
 for k in keys:

@@ -128,14 +128,27 @@ __global__ void __launch_bounds__(256) k_norm_bwd_stats8(const uint4* __restrict
         mean[e] = stat[c0 + e]; rstd[e] = stat[C + c0 + e]; sc[e] = stat[2 * C + c0 + e]; sh[e] = stat[3 * C + c0 + e];
         s1[e] = 0.f; s2[e] = 0.f;
     }
-    for (int64_t v = v0 + lane; v < v1; v += NV) {
+    for (int64_t v = v0 + lane; v < v1; v += 2 * NV) {     // two voxels per trip: four 16-B loads in flight per thread
+        const bool two = v + NV < v1;
+        const uint4 ru0 = u8[v * G8 + grp], rg0 = g8[v * G8 + grp];
+        uint4 ru1 = ru0, rg1 = make_uint4(0u, 0u, 0u, 0u);
+        if (two) { ru1 = u8[(v + NV) * G8 + grp]; rg1 = g8[(v + NV) * G8 + grp]; }
         float uf[8], gf[8];
-        unpack8(u8[v * G8 + grp], uf);
-        unpack8(g8[v * G8 + grp], gf);
+        unpack8(ru0, uf);
+        unpack8(rg0, gf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float dv = gf[e] * act_d(fmaf(uf[e], sc[e], sh[e]), act);
             s1[e] += dv; s2[e] = fmaf(dv, (uf[e] - mean[e]) * rstd[e], s2[e]);
+        }
+        if (two) {
+            unpack8(ru1, uf);
+            unpack8(rg1, gf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float dv = gf[e] * act_d(fmaf(uf[e], sc[e], sh[e]), act);
+                s1[e] += dv; s2[e] = fmaf(dv, (uf[e] - mean[e]) * rstd[e], s2[e]);
+            }
         }
     }
 #pragma unroll
@@ -227,23 +240,31 @@ void launch_norm_bwd_partial(int dtype, void* g, const void* u, int C, int64_t S
     UNET_DISPATCH(dtype, (k_stats_partial<T, 1><<<nb, 256, 0, s>>>((const T*)u, (T*)g, C, S, stats_vpb(S), pow2_ge(C), stat, act, partial)));
 }
 
+// block of 256 threads (4 waves): shuffle tree inside each wave, the four wave sums added in wave order by thread 0
 __device__ __forceinline__ void reduce2_wave(double& a, double& b) {
+    __shared__ double wred[4][2];
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6][0] = a; wred[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = wred[0][0]; b = wred[0][1];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { a += wred[w][0]; b += wred[w][1]; }
+    }
 }
 
-// one wave per channel
+// one block (1 or 4 waves) per channel
 // block partials [blk][C][2]: float, or (dbl) double as k_stats_partial leaves them for fp32 tensors
 __device__ __forceinline__ void sum_partials(const float* __restrict__ partial, int dbl, int nblk, int C, int c, double& a, double& b) {
     a = 0.0; b = 0.0;
     if (dbl) {
         const double* pd = (const double*)partial;
-        for (int i = threadIdx.x; i < nblk; i += 64) { a += pd[((int64_t)i * C + c) * 2]; b += pd[((int64_t)i * C + c) * 2 + 1]; }
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) { a += pd[((int64_t)i * C + c) * 2]; b += pd[((int64_t)i * C + c) * 2 + 1]; }
     } else {
-        for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) { a += partial[((int64_t)i * C + c) * 2]; b += partial[((int64_t)i * C + c) * 2 + 1]; }
     }
 }
 
-__global__ void __launch_bounds__(64) k_norm_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
+__global__ void __launch_bounds__(256) k_norm_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
                                                       const float* gamma, const float* beta, double eps, float* stat, float* rm,
                                                       float* rv, double momentum, int dbl) {
     int c = blockIdx.x;
@@ -264,11 +285,11 @@ __global__ void __launch_bounds__(64) k_norm_finalize(const float* __restrict__ 
 }
 void launch_norm_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
                           float* stat, float* rm, float* rv, double momentum, hipStream_t s, bool dbl) {
-    k_norm_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, beta, eps, stat, rm, rv, momentum, dbl ? 1 : 0);
+    k_norm_finalize<<<C, nblk > 128 ? 256 : 64, 0, s>>>(partial, nblk, C, S, gamma, beta, eps, stat, rm, rv, momentum, dbl ? 1 : 0);
 }
 
 // out[c][j] = sum over blocks of partial[blk][c][j]   (one wave per channel, fp64, fixed order)
-__global__ void __launch_bounds__(64) k_stats_sum(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int dbl) {
+__global__ void __launch_bounds__(256) k_stats_sum(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out, int dbl) {
     int c = blockIdx.x;
     double a, b;
     sum_partials(partial, dbl, nblk, C, c, a, b);
@@ -276,7 +297,7 @@ __global__ void __launch_bounds__(64) k_stats_sum(const float* __restrict__ part
     if (threadIdx.x == 0) { out[c * 2] = (float)a; out[c * 2 + 1] = (float)b; }
 }
 void launch_stats_sum(const float* partial, int nblk, int C, float* out, hipStream_t s, bool dbl) {
-    k_stats_sum<<<C, 64, 0, s>>>(partial, nblk, C, out, dbl ? 1 : 0);
+    k_stats_sum<<<C, nblk > 128 ? 256 : 64, 0, s>>>(partial, nblk, C, out, dbl ? 1 : 0);
 }
 
 __global__ void k_norm_eval(int C, const float* gamma, const float* beta, const float* rm, const float* rv, double eps, float* stat) {
@@ -290,7 +311,7 @@ void launch_norm_eval(int C, const float* gamma, const float* beta, const float*
     k_norm_eval<<<(C + 63) / 64, 64, 0, s>>>(C, gamma, beta, rm, rv, eps, stat);
 }
 
-__global__ void __launch_bounds__(64) k_norm_bwd_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
+__global__ void __launch_bounds__(256) k_norm_bwd_finalize(const float* __restrict__ partial, int nblk, int C, int64_t S,
                                                           const float* gamma, const float* stat, float* coef, float* dgamma,
                                                           float* dbeta, int dbl) {
     int c = blockIdx.x;
@@ -307,7 +328,7 @@ __global__ void __launch_bounds__(64) k_norm_bwd_finalize(const float* __restric
 }
 void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat, float* coef,
                               float* dgamma, float* dbeta, hipStream_t s, bool dbl) {
-    k_norm_bwd_finalize<<<C, 64, 0, s>>>(partial, nblk, C, S, gamma, stat, coef, dgamma, dbeta, dbl ? 1 : 0);
+    k_norm_bwd_finalize<<<C, nblk > 128 ? 256 : 64, 0, s>>>(partial, nblk, C, S, gamma, stat, coef, dgamma, dbeta, dbl ? 1 : 0);
 }
 
 template <typename T> __global__ void k_norm_bwd_apply(T* __restrict__ g, const T* __restrict__ u, int C, int64_t n,
@@ -634,24 +655,17 @@ void launch_loss_partial(const float* logits, const int64_t* target, int C, int6
 __global__ void __launch_bounds__(256) k_loss_finalize(const float* __restrict__ partial, int nblk, int oc, float weight, int cost_mask,
                                                        float* level_out, float* totals, int set_stats) {
     extern __shared__ double shd[];  // 3 + 2*oc
-    __shared__ double redd[256];
     int np = 3 + 2 * oc;
-    // 16 values x 16 split lanes per pass (fixed order): one pass for out_count <= 6 instead of np block-wide tree reductions
-    const int vi = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    for (int i0 = 0; i0 < np; i0 += 16) {
-        const int i = i0 + vi;
+    // one wave per value, 64 row lanes (<= 16 rows each at 1024 blocks), shuffle tree: fixed order.  (16 values x 16 split lanes with
+    // 64 dependent 4-byte loads per thread took 18 us at the two largest levels.)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    for (int i = wv; i < np; i += 4) {
         double a = 0.0;
-        if (i < np)
-            for (int b = ly; b < nblk; b += 16) a += partial[(int64_t)b * np + i];
-        redd[threadIdx.x] = a;
-        __syncthreads();
-        if (ly == 0 && i < np) {
-            double t = 0.0;
-            for (int k = 0; k < 16; ++k) t += redd[k * 16 + vi];
-            shd[i] = t;
-        }
-        __syncthreads();
+        for (int b = ln; b < nblk; b += 64) a += partial[(int64_t)b * np + i];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+        if (ln == 0) shd[i] = a;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double n = shd[2] < 1.0 ? 1.0 : shd[2];
         double eps = (double)1e-5f, dsum = 0.0;

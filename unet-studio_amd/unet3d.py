@@ -107,6 +107,10 @@ class UNet3d:
         for i in range(1, len(self._buffers), 2):
             self._buffers[i].fill_(1.0)  # running_var
         self.num_batches_tracked = 0
+        # host arrays of device pointers (unet_forward / unet_backward arguments): the flat buffers never move, build them once
+        self._pp = E.ptr_array([p.data_ptr() for p in self._params])
+        self._gp = E.ptr_array([g.data_ptr() for g in self._grads])
+        self._bp = E.ptr_array([b.data_ptr() for b in self._buffers]) if self._buffers else None
         self._trigger = torch.zeros(1, device=self._device, requires_grad=True)
         self.reset_parameters(seed)
 
@@ -249,8 +253,7 @@ class UNet3d:
 
     def _run_forward(self, plan, ws, x, mode):
         outs = [torch.empty(s, dtype=torch.float32, device=self._device) if s[1] > 0 else None for s in plan.output_shapes]
-        pp = E.ptr_array([p.data_ptr() for p in self._params])
-        bp = E.ptr_array([b.data_ptr() for b in self._buffers]) if self._buffers else None
+        pp, bp = self._pp, self._bp
         op = E.ptr_array([o.data_ptr() if o is not None else None for o in outs])
         E.check(E.lib.unet_forward(plan.handle, pp, bp, x.data_ptr(), op, ws.data_ptr(), mode, _stream_ptr(self._device)))
         if mode == 1 and self._buffers:
@@ -258,15 +261,13 @@ class UNet3d:
         return outs
 
     def _run_backward(self, plan, ws, grad_outs, grad_x=None):
-        pp = E.ptr_array([p.data_ptr() for p in self._params])
-        gp = E.ptr_array([g.data_ptr() for g in self._grads])
+        pp, gp = self._pp, self._gp
         go = E.ptr_array([g.data_ptr() if g is not None else None for g in grad_outs])
         E.check(E.lib.unet_backward(plan.handle, pp, go, gp, grad_x.data_ptr() if grad_x is not None else None,
                                     ws.data_ptr(), _stream_ptr(self._device)))
 
     def _run_backward_part(self, plan, ws, grad_outs, op_hi, op_lo):
-        pp = E.ptr_array([p.data_ptr() for p in self._params])
-        gp = E.ptr_array([g.data_ptr() for g in self._grads])
+        pp, gp = self._pp, self._gp
         go = E.ptr_array([g.data_ptr() if g is not None else None for g in grad_outs])
         E.check(E.lib.unet_backward_part(plan.handle, pp, go, gp, None, ws.data_ptr(), op_hi, op_lo, _stream_ptr(self._device)))
 
