@@ -130,6 +130,12 @@ int unet_loss_scratch_bytes(const unet_plan* plan, size_t* bytes);
 int unet_loss(const unet_plan* plan, const float* const* outs, const int64_t* target, int cost_mask, int collapse_before,
               float* const* grad_outs, float* losses_out, void* scratch, void* stream);
 
+/* unet_forward (mode 1) + unet_loss in one call.  Same results as the two calls; the engine may issue the loss of the coarse
+ * deep-supervision levels beside the rest of the decoder (train.cpp:628 followed by :634-706 for one sample). */
+int unet_forward_loss(const unet_plan* plan, const float* const* params, float* const* buffers, const float* x, float* const* outs,
+                      const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
+                      void* loss_scratch, void* workspace, void* stream);
+
 /* step epilogue over flat buffers (train.cpp:759-766 + SGD(momentum, nesterov, weight decay) of
  * unet.cpp:254-275): g *= grad_scale (1/batch_size); coef = min(1, clip_norm/(||g||+1e-6));
  * d = coef*g + wd*p (wd only on decay parameters); m = momentum*m + d; p -= lr*(d + momentum*m) (nesterov)

@@ -626,3 +626,30 @@ def test_nz_file_round_trip_through_the_engine(tmp_path):
     x, _ = U.SyntheticVolumes(1, 3, (16, 16, 16), DEV)(0)
     m.eval(); r.eval()
     assert torch.equal(m.forward(x)[0], r.forward(x)[0])
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_fused_forward_loss_equals_the_two_calls(dt):
+    """unet_forward_loss (forward + calc_losses in one call, coarse levels' loss on the plan's side stream) against unet_forward
+    followed by unet_loss: identical logits and identical dL/dlogits at every level; the total only differs by the order in which
+    the five weighted level losses are added."""
+    arch = U.default_feature(4)
+    m = U.UNet3d(1, 4, arch, device=DEV, dtype=dt, seed=1)
+    x, t = U.SyntheticVolumes(1, 4, (32, 32, 32), DEV)(3)
+    plan = m.plan_for((32, 32, 32))
+    ws = m._workspace(plan)
+    outs_a = m._run_forward(plan, ws, x, mode=1)
+    losses_a, g_a = m.loss(outs_a, t, True, True, True, 0, plan=plan)
+    outs_a = [o.clone() for o in outs_a]; g_a = [g.clone() for g in g_a]; losses_a = losses_a.clone()
+    outs_b, losses_b, g_b = m._run_forward_loss(plan, ws, x, t, True, True, True, 0)
+    torch.cuda.synchronize()
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    for a, b in zip(g_a, g_b):
+        assert torch.equal(a, b)
+    assert torch.equal(losses_a[1:], losses_b[1:])                       # level-0 ce, dice, mse
+    assert abs(float(losses_a[0]) - float(losses_b[0])) <= 2e-6 * abs(float(losses_a[0]))
+    # and it is reproducible from run to run (two streams, fixed summation order)
+    _, losses_c, g_c = m._run_forward_loss(plan, ws, x, t, True, True, True, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(losses_b, losses_c) and all(torch.equal(a, b) for a, b in zip(g_b, g_c))

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -239,14 +240,17 @@ struct unet_plan {
         }
         wgrad_off = take(wmax ? wmax : 256);
         head_off = take(hmax ? hmax : 256);
+        // every matrix-core weight gradient keeps a slab region of its own until the batched reduce of the backward (part)
         wz_off.assign(g.ops.size(), SIZE_MAX);
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
-            if (op.kind != OP_CONV || impl != UNET_IMPL_AUTO || !wgrad_mfma[i]) continue;
+            if ((op.kind != OP_CONV && op.kind != OP_CONVT) || impl != UNET_IMPL_AUTO || op.out_level >= 0) continue;
             ConvGeom cg = op_geom_of(op);
             SrcDesc sd[2];
             for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
-            if (mfma_wgrad_z_supported(dtype, cg, sd, op.nsrc)) wz_off[i] = take(mfma_wgrad_z_scratch_bytes(cg));
+            if (op.kind == OP_CONV && conv_first_wgrad_mfma_supported(dtype, cg, sd, op.nsrc)) wz_off[i] = take(conv_first_wgrad_mfma_scratch_bytes(cg));
+            else if (op.kind == OP_CONV && wgrad_mfma[i]) wz_off[i] = take(mfma_wgrad_scratch_bytes(cg));
+            else if (op.kind == OP_CONVT && wgrad_mfma[i]) wz_off[i] = take(mfma_convt_wgrad_scratch_bytes(cg));
         }
         ws_bytes = off;
         // batched filter pack: one job per MFMA filter pack, sources as offsets into a flat parameter buffer
@@ -265,13 +269,19 @@ struct unet_plan {
             ConvGeom cg = op_geom_of(op);
             WgradReduceJob j;
             j.op = (int)i;
-            j.nsplit = mfma_wgrad_z_splits(cg);
-            j.n = (long long)27 * op.cin * op.cout;
-            j.Cb = op.cout;
             j.slab_off = (long long)(wz_off[i] / 4);
-            j.bias_off = op.bias >= 0 ? j.slab_off + (long long)j.nsplit * j.n : -1;
             j.dw_off = p_off[op.weight];
-            j.db_off = op.bias >= 0 ? p_off[op.bias] : -1;
+            j.Cb = op.cout;
+            if (op.kind == OP_CONVT) {   // bias gradient of a conv_trans: launch_bias_grad, not part of the slab
+                j.nsplit = mfma_convt_wgrad_splits(cg);
+                j.n = (long long)8 * op.cin * op.cout;
+                j.bias_off = -1; j.db_off = -1;
+            } else {
+                j.nsplit = (op.cin == 1) ? conv_first_wgrad_splits(cg) : mfma_conv_wgrad_splits(cg);
+                j.n = (long long)27 * op.cin * op.cout;
+                j.bias_off = op.bias >= 0 ? j.slab_off + (long long)j.nsplit * j.n : -1;
+                j.db_off = op.bias >= 0 ? p_off[op.bias] : -1;
+            }
             wz_blk += wgrad_reduce_job_blocks(j, wz_blk);
             wz_job_of_op[i] = (int)wz_jobs.size();
             wz_jobs.push_back(j);
@@ -336,7 +346,9 @@ struct Exec {
         return g;
     }
 
-    void forward(const float* const* params, float* const* buffers, const float* x, float* const* outs, int mode) {
+    // on_head(level): called right after the launches that produce results[level] (a fused forward + loss issues that level's loss there)
+    void forward(const float* const* params, float* const* buffers, const float* x, float* const* outs, int mode,
+                 const std::function<void(int)>* on_head = nullptr) {
         const Graph& g = p.g;
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
         // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
@@ -467,6 +479,8 @@ struct Exec {
                 const Tensor& T = g.tensors[op.dst];
                 if (T.norm < 0 && T.act != ACT_NONE) apply_view(op.dst);
             }
+            if (on_head && op.out_level >= 0 && outs && outs[op.out_level] && (op.kind == OP_CONV || op.kind == OP_CONVT || op.kind == OP_EXPORT))
+                (*on_head)(op.out_level);
         }
         need_packs();   // nothing consumed the packs (no MFMA op): still order the caller's stream after the side stream
     }
@@ -518,6 +532,22 @@ struct Exec {
         bool gflat = p.wz_jobs_dev != nullptr;
         for (size_t k = 0; k < g.params.size() && gflat; ++k) gflat = gparams[k] == gparams[0] + p.p_off[k];
         std::vector<char> wz_ran(p.wz_jobs.size(), 0);
+        int wz_pending = 0;
+        // slabs of the weight gradients launched so far -> gradients: one launch per run of consecutive jobs (normally one).  Flushed
+        // every few layers, not only at the end: a single reduce of everything would sit behind the last layer on the side stream
+        // and the caller's stream waits for it at the join.
+        auto flush_wz = [&](hipStream_t st) {
+            for (size_t j = 0; j < wz_ran.size();) {
+                if (!wz_ran[j]) { ++j; continue; }
+                size_t e = j;
+                int nblk = 0;
+                while (e < wz_ran.size() && wz_ran[e]) { nblk += p.wz_jobs[e].nblk; wz_ran[e] = 0; ++e; }
+                ProfScope pr(-1, UNET_PROF_WGRAD, st);
+                launch_wgrad_reduce_batched(p.wz_jobs_dev, (int)j, (int)(e - j), p.wz_jobs[j].blk0, nblk, ws, gparams[0], st);
+                j = e;
+            }
+            wz_pending = 0;
+        };
         for (int i = (int)g.ops.size() - 1; i >= op_lo; --i) {
             const Op& op = g.ops[i];
             const bool dry = i >= op_hi;
@@ -558,14 +588,17 @@ struct Exec {
                     if (op.kind == OP_CONV) {
                         ProfScope* pw = dry ? nullptr : new ProfScope(i, UNET_PROF_WGRAD, sb);
                         if (dry) {
-                        } else if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc))
-                            launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
-                        else if (p.wgrad_mfma[i] && gflat && p.wz_job_of_op[i] >= 0) {
-                            launch_mfma_wgrad_z(cg, sd, op.nsrc, gptr(t), op.bias >= 0, ws + p.wz_off[i], sb);
-                            wz_ran[p.wz_job_of_op[i]] = 1;
-                        } else if (p.wgrad_mfma[i])
+                        } else if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
+                            const bool defer = gflat && p.wz_job_of_op[i] >= 0;
+                            launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias],
+                                                         ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                            if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
+                        } else if (p.wgrad_mfma[i]) {
+                            const bool defer = gflat && p.wz_job_of_op[i] >= 0;   // slab only: summed by the batched reduce below
                             launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias],
-                                                   ws + (p.wz_off[i] != SIZE_MAX ? p.wz_off[i] : p.wgrad_off), sb);
+                                                   ws + (p.wz_off[i] != SIZE_MAX ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                            if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
+                        }
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
                             launch_wgrad_f32_mfma(cg, sd, op.nsrc, (const float*)gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
@@ -573,6 +606,8 @@ struct Exec {
                         else
                             launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
                         delete pw;
+                        static const int wz_every = getenv("UNET_WZ_FLUSH") ? atoi(getenv("UNET_WZ_FLUSH")) : 3;   // experiment knob
+                        if (wz_pending >= wz_every) flush_wz(sb);
                         ProfScope pd(i, UNET_PROF_DGRAD, s);
                         if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (!dry && any && p.impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(p.dtype, cg, dg, op.nsrc))
@@ -581,7 +616,9 @@ struct Exec {
                     } else {
                         ProfScope* pw = dry ? nullptr : new ProfScope(i, UNET_PROF_WGRAD, sb);
                         if (p.wgrad_mfma[i]) {
-                            if (!dry) launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + p.wgrad_off, sb);
+                            const bool defer = gflat && p.wz_job_of_op[i] >= 0;
+                            if (!dry) launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                            if (!dry && defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
                             if (!dry) launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
                         } else {
                             if (!dry) launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
@@ -621,16 +658,7 @@ struct Exec {
                 default: break;
             }
         }
-        // the slabs of this call's sliding-window wgrads -> gradients: one launch per run of consecutive jobs (normally one)
-        for (size_t j = 0; j < wz_ran.size();) {
-            if (!wz_ran[j]) { ++j; continue; }
-            size_t e = j;
-            int nblk = 0;
-            while (e < wz_ran.size() && wz_ran[e]) { nblk += p.wz_jobs[e].nblk; ++e; }
-            ProfScope pr(-1, UNET_PROF_WGRAD, sb);
-            launch_wgrad_reduce_batched(p.wz_jobs_dev, (int)j, (int)(e - j), p.wz_jobs[j].blk0, nblk, ws, gparams[0], sb);
-            j = e;
-        }
+        flush_wz(sb);
         if (sb != s) {   // join: whatever the caller enqueues next (optimizer step, next forward) sees every gradient
             HIP_OK(hipEventRecord(p.ev_join, sb));
             HIP_OK(hipStreamWaitEvent(s, p.ev_join, 0));
@@ -692,7 +720,8 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
                 off = align_up(off + (size_t)(4 + 2 * oc) * 4);                    // level_out
                 (void)o;
             }
-            off = align_up(off + (size_t)1024 * (3 + 2 * oc) * 4);                // partials
+            off = align_up(off + (size_t)1024 * (3 + 2 * oc) * 4);                // partials (level 0 ...)
+            off = align_up(off + (size_t)1024 * (3 + 2 * oc) * 4);                // ... and the coarse levels, which may run on another stream
             p->loss_bytes = off;
         }
         // sgd segment table
@@ -904,39 +933,46 @@ int unet_profile_end(int max_records, int* op_index, int* category, float* ms, i
 
 int unet_loss_scratch_bytes(const unet_plan* p, size_t* bytes) { *bytes = p->loss_bytes; return 0; }
 
-int unet_loss(const unet_plan* p, const float* const* outs, const int64_t* target, int cost_mask, int collapse_before,
-              float* const* grad_outs, float* losses_out, void* scratch, void* stream) {
-    try {
+namespace {
+// calc_losses + the deep-supervision loop (train.cpp:501-552,634-706) in pieces, so that a fused forward + loss can issue a level's
+// kernels as soon as its head is computed, on another stream: prepare() = totals reset + target pyramid; level_partial /
+// level_finish = one level.  Levels that may run concurrently must use different partial areas (`area`).
+struct LossRun {
+    const unet_plan* p;
+    const float* const* outs; const int64_t* target; float* const* grad_outs; float* losses_out;
+    int C, oc, collapse, cost_mask;
+    float inv;
+    std::vector<int64_t*> tgt;
+    std::vector<float*> lvl;
+    float* partial[2];
+    LossRun(const unet_plan* plan, const float* const* outs_, const int64_t* target_, int cost_mask_, int collapse_before, float* const* grad_outs_,
+            float* losses_out_, void* scratch)
+        : p(plan), outs(outs_), target(target_), grad_outs(grad_outs_), losses_out(losses_out_), collapse(collapse_before), cost_mask(cost_mask_) {
         if (!p || !outs || !target || !losses_out || !scratch) throw std::runtime_error("unet_loss: null argument");
         const Graph& g = p->g;
-        int C = g.out_c;
+        C = g.out_c;
         if (collapse_before < 0 || collapse_before >= C) throw std::runtime_error("invalid collapse_before");
-        int oc = collapse_before ? C - collapse_before + 1 : C;
-        DeviceGuard dg(p->device);
-        hipStream_t s = (hipStream_t)stream;
-        size_t nl = g.outputs.size();
+        oc = collapse_before ? C - collapse_before + 1 : C;
+        const size_t nl = g.outputs.size();
         float wsum = 0.f;
         for (size_t k = 0; k < nl; ++k) wsum += 1.0f / (float)(1 << k);
-        float inv = 1.0f / wsum;
-        HIP_OK(hipMemsetAsync(losses_out, 0, 4 * sizeof(float), s));
+        inv = 1.0f / wsum;
         char* sc = (char*)scratch;
         size_t off = 0;
-        std::vector<int64_t*> tgt(nl);
-        std::vector<float*> lvl(nl);
+        tgt.resize(nl); lvl.resize(nl);
         for (size_t l = 0; l < nl; ++l) {
             int64_t S = (int64_t)(g.D >> l) * (g.H >> l) * (g.W >> l);
             if (S <= 0) S = 1;
             tgt[l] = (int64_t*)(sc + off); off = align_up(off + (size_t)S * 8);
             lvl[l] = (float*)(sc + off); off = align_up(off + (size_t)(4 + 2 * C) * 4);
         }
-        float* partial = (float*)(sc + off);
-        const int64_t* cur = target;
+        partial[0] = (float*)(sc + off); off = align_up(off + (size_t)1024 * (3 + 2 * C) * 4);
+        partial[1] = (float*)(sc + off);
         int D = g.D, H = g.H, W = g.W;
-        for (size_t k = 0; k < nl; ++k) {
+        for (size_t k = 0; k < nl; ++k) {      // the reference's run-time checks (train.cpp:651-652,664-671), before anything is launched
             if (k > 0) {
                 if ((D >> 1) <= 0 || (H >> 1) <= 0 || (W >> 1) <= 0) throw std::runtime_error("deep supervision target size became zero");
-                launch_target_half(cur, tgt[k], D, H, W, s);
-                cur = tgt[k]; D >>= 1; H >>= 1; W >>= 1;
+                D >>= 1; H >>= 1; W >>= 1;
             }
             const auto& o = g.outputs[k];
             if (o.C == 0 || !outs[k]) throw std::runtime_error("undefined deep supervision output at level " + std::to_string(k));
@@ -944,12 +980,85 @@ int unet_loss(const unet_plan* p, const float* const* outs, const int64_t* targe
                 throw std::runtime_error("output channel mismatch at level " + std::to_string(k) + ": tensor has " + std::to_string(o.C) +
                                          ", out_count is " + std::to_string(C));
             if (o.D != D || o.H != H || o.W != W) throw std::runtime_error("deep supervision output/target size mismatch at level " + std::to_string(k));
-            int64_t S = (int64_t)D * H * W;
-            float w = (1.0f / (float)(1 << k)) * inv;
-            launch_loss_partial(outs[k], cur, C, S, collapse_before, partial, s);
-            launch_loss_finalize(partial, loss_blocks(S), oc, w, cost_mask, lvl[k], losses_out, k == 0, s);
-            if (grad_outs && grad_outs[k]) launch_loss_grad(outs[k], cur, C, S, collapse_before, lvl[k], w, cost_mask, grad_outs[k], s);
         }
+    }
+    size_t levels() const { return p->g.outputs.size(); }
+    const int64_t* target_of(size_t k) const { return k == 0 ? target : tgt[k]; }
+    int64_t voxels(size_t k) const { const auto& o = p->g.outputs[k]; return (int64_t)o.D * o.H * o.W; }
+    void prepare(hipStream_t s) {
+        HIP_OK(hipMemsetAsync(losses_out, 0, 4 * sizeof(float), s));
+        const Graph& g = p->g;
+        int D = g.D, H = g.H, W = g.W;
+        for (size_t k = 1; k < levels(); ++k) {
+            launch_target_half(target_of(k - 1), tgt[k], D, H, W, s);
+            D >>= 1; H >>= 1; W >>= 1;
+        }
+    }
+    void level_partial(size_t k, int area, hipStream_t s) { launch_loss_partial(outs[k], target_of(k), C, voxels(k), collapse, partial[area], s); }
+    void level_finish(size_t k, int area, hipStream_t s) {
+        const float w = (1.0f / (float)(1 << k)) * inv;
+        launch_loss_finalize(partial[area], loss_blocks(voxels(k)), oc, w, cost_mask, lvl[k], losses_out, k == 0, s);
+        if (grad_outs && grad_outs[k]) launch_loss_grad(outs[k], target_of(k), C, voxels(k), collapse, lvl[k], w, cost_mask, grad_outs[k], s);
+    }
+};
+}  // namespace
+
+int unet_loss(const unet_plan* p, const float* const* outs, const int64_t* target, int cost_mask, int collapse_before,
+              float* const* grad_outs, float* losses_out, void* scratch, void* stream) {
+    try {
+        LossRun lr(p, outs, target, cost_mask, collapse_before, grad_outs, losses_out, scratch);
+        DeviceGuard dg(p->device);
+        hipStream_t s = (hipStream_t)stream;
+        lr.prepare(s);
+        for (size_t k = 0; k < lr.levels(); ++k) { lr.level_partial(k, 0, s); lr.level_finish(k, 0, s); }
+        check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+// unet_forward (train mode) + unet_loss in one call, which lets the loss of the coarse levels leave the critical path: the target
+// pyramid is built on the plan's side stream while the encoder runs, and the loss kernels of level k >= 1 are issued there as soon as
+// head k exists (the decoder's remaining levels run meanwhile on the caller's stream).  Level 0 stays on the caller's stream; its
+// finalize comes after the join, so totals[0] is summed in a fixed order (levels 1.. then 0) and stays bit-reproducible.
+int unet_forward_loss(const unet_plan* p, const float* const* params, float* const* buffers, const float* x, float* const* outs,
+                      const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
+                      void* loss_scratch, void* workspace, void* stream) {
+    try {
+        if (!p || !params || !x || !workspace || !outs) throw std::runtime_error("unet_forward_loss: null argument");
+        if (!p->g.buffers.empty() && !buffers) throw std::runtime_error("unet_forward_loss: architecture has bnorm layers but buffers is null");
+        LossRun lr(p, outs, target, cost_mask, collapse_before, grad_outs, losses_out, loss_scratch);
+        DeviceGuard dg(p->device);
+        hipStream_t s = (hipStream_t)stream;
+        static const bool no_side = getenv("UNET_NO_SIDE_STREAM") != nullptr;
+        const bool side = p->side && !no_side && !g_prof;
+        Exec ex(*p, workspace, stream);
+        if (!side) {
+            ex.forward(params, buffers, x, outs, 1);
+            lr.prepare(s);
+            for (size_t k = 0; k < lr.levels(); ++k) { lr.level_partial(k, 0, s); lr.level_finish(k, 0, s); }
+            check_launch();
+            return 0;
+        }
+        hipStream_t sd = p->side;
+        bool prepared = false;
+        std::function<void(int)> on_head = [&](int level) {
+            if (level < 1 || (size_t)level >= lr.levels()) return;
+            HIP_OK(hipEventRecord(p->ev_fork, s));             // results[level] is final on the caller's stream here (and so is `target`)
+            HIP_OK(hipStreamWaitEvent(sd, p->ev_fork, 0));
+            if (!prepared) { lr.prepare(sd); prepared = true; }   // not at entry: the forward's filter pack goes first on the side stream
+            lr.level_partial((size_t)level, 1, sd);
+            lr.level_finish((size_t)level, 1, sd);
+        };
+        ex.forward(params, buffers, x, outs, 1, &on_head);
+        if (!prepared) {   // a single-level architecture: nothing went to the side stream
+            HIP_OK(hipEventRecord(p->ev_fork, s));
+            HIP_OK(hipStreamWaitEvent(sd, p->ev_fork, 0));
+            lr.prepare(sd);
+        }
+        lr.level_partial(0, 0, s);
+        HIP_OK(hipEventRecord(p->ev_join, sd));
+        HIP_OK(hipStreamWaitEvent(s, p->ev_join, 0));
+        lr.level_finish(0, 0, s);
         check_launch();
         return 0;
     } catch (const std::exception& e) { return fail(e.what()); }

@@ -160,8 +160,12 @@ void launch_wgrad_reduce_batched(const WgradReduceJob* jobs_dev, int job0, int n
                                  hipStream_t s);
 bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
+// defer_reduce: only the slab ([rows][n] + [rows][Cout] bias partials at `scratch`) is written; rows = *_wgrad_splits(g)
+int mfma_conv_wgrad_splits(const ConvGeom& g);
+int mfma_convt_wgrad_splits(const ConvGeom& g);
+int conv_first_wgrad_splits(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
-                            hipStream_t s);
+                            hipStream_t s, bool defer_reduce = false);
 // wgrad of layers with <= 1024 weights (Cin = 1 first conv, 6-channel heads): row-staged, HBM-bound
 // 1x1x1 heads (Cout <= 8, Cin = 16 * 2^k <= 256, one plain or viewed source): forward writes results[level] (fp32 NCDHW) and/or
 // the channels-last tensor; backward = dL/dW (+=), dL/db (+=) and dL/d(source view) in one pass, dy as fp32 NCDHW or channels-last
@@ -174,7 +178,8 @@ void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const flo
 // wgrad (+ bias grad) of the first conv (Cin = 1, 3x3x3 stride 1, Cout 16 or 32, plain bf16 input) on the matrix cores
 bool conv_first_wgrad_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g);
-void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s);
+void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s,
+                                  bool defer_reduce = false);
 bool wgrad_small_supported(const ConvGeom& g, int nsrc);
 size_t wgrad_small_scratch_bytes(const ConvGeom& g);
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
@@ -182,7 +187,8 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
 // conv_trans wgrad (single source); bias grad separately (launch_bias_grad)
 bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g);
-void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s);
+void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s,
+                             bool defer_reduce = false);
 // vectorised per-block column sums partial[blk][C] of a bf16 [S][C] tensor; returns #blocks (0: not applicable)
 int launch_colsum_partial8(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s);
 size_t bias_grad_scratch_bytes(int C, int64_t S);

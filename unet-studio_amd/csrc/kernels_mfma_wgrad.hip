@@ -565,7 +565,9 @@ static int first_wgrad_blocks(const ConvGeom& g) {
 }
 size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g) { return (size_t)first_wgrad_blocks(g) * (27 * g.Cout + g.Cout) * 4 + 256; }
 // dw += , db += (db may be null); scratch: conv_first_wgrad_mfma_scratch_bytes
-void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s) {
+int conv_first_wgrad_splits(const ConvGeom& g) { return first_wgrad_blocks(g); }
+void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s,
+                                  bool defer_reduce) {
     FirstWgradArgs a;
     a.g = g; a.x = src[0].ptr; a.dy = dy; a.slab = (float*)scratch;
     a.tiles_x = (g.W + 31) / 32; a.tiles_y = (g.H + 7) / 8; a.tiles_z = (g.D + 1) / 2;
@@ -574,7 +576,7 @@ void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const v
     a.bslab = a.slab + (size_t)nb * O;
     if (g.Cout == 16) k_wgrad_first_mfma<1><<<nb, 256, 0, s>>>(a);
     else k_wgrad_first_mfma<2><<<nb, 256, 0, s>>>(a);
-    wgrad_reduce(a.slab, db ? a.bslab : nullptr, nb, O, g.Cout, dw, db, s);
+    if (!defer_reduce) wgrad_reduce(a.slab, db ? a.bslab : nullptr, nb, O, g.Cout, dw, db, s);
 }
 
 static bool chan16(const ConvGeom& g, const SrcDesc* src, int nsrc) {
@@ -655,12 +657,20 @@ static void launch_wgrad_p(const MfmaWgradArgs& a, const WgradCfg& c, hipStream_
     }
 }
 
+// rows of the slab a launch leaves at `scratch` ([rows][27*Cin*Cout], then [rows][Cout] bias partials): plan-time constant
+int mfma_conv_wgrad_splits(const ConvGeom& g) {
+    if (int z = mfma_wgrad_z_splits(g)) return z;
+    return wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo).nsplit;
+}
+int mfma_convt_wgrad_splits(const ConvGeom& g) { return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).nsplit; }
+// defer_reduce: leave the slab for the caller's batched reduce (launch_wgrad_reduce_batched) instead of summing it here
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
-                            hipStream_t s) {
+                            hipStream_t s, bool defer_reduce) {
     if (mfma_wgrad_z_supported(1, g, src, nsrc)) {   // sliding-window kernel (kernels_mfma_wgrad_z.hip): stride 1, W >= 24
         const int ns = launch_mfma_wgrad_z(g, src, nsrc, dy, db != nullptr, scratch, s);
         const float* slab = (const float*)scratch;
-        wgrad_reduce(slab, db ? slab + (size_t)ns * 27 * g.Cin * g.Cout : nullptr, ns, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
+        if (!defer_reduce)
+            wgrad_reduce(slab, db ? slab + (size_t)ns * 27 * g.Cin * g.Cout : nullptr, ns, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
         return;
     }
     WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
@@ -679,12 +689,12 @@ void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, con
         else if (g.Wo > 4) launch_wgrad_p<2, 3, 1, 2, 8, 8>(a, c, s);
         else launch_wgrad_p<2, 3, 1, 4, 8, 4>(a, c, s);
     }
-    wgrad_reduce(a.slab, a.bias_slab, c.nsplit, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
+    if (!defer_reduce) wgrad_reduce(a.slab, a.bias_slab, c.nsplit, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
 }
 
 // conv_trans wgrad (g = forward geometry of the conv_trans: D,H,W coarse input, Do,Ho,Wo fine output).
 // halo side A = dy (fine, Cout channels), tile side B = transformed input (coarse, Cin channels): D_t[co][ci].
-void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s) {
+void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s, bool defer_reduce) {
     WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
     MfmaWgradArgs a;
     a.g.Cin = g.Cout; a.g.Cout = g.Cin; a.g.D = g.Do; a.g.H = g.Ho; a.g.W = g.Wo; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
@@ -697,7 +707,7 @@ void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* 
     else if (g.W > 4) launch_wgrad_p<2, 2, 0, 2, 8, 8>(a, c, s);
     else launch_wgrad_p<2, 2, 0, 4, 8, 4>(a, c, s);
     // slab[cb = ci][ca = co][t] = the layout of dw ([Cin][Cout][2][2][2])
-    wgrad_reduce(a.slab, nullptr, c.nsplit, (int64_t)8 * g.Cin * g.Cout, g.Cin, dw, nullptr, s);
+    if (!defer_reduce) wgrad_reduce(a.slab, nullptr, c.nsplit, (int64_t)8 * g.Cin * g.Cout, g.Cin, dw, nullptr, s);
 }
 
 }  // namespace unet

@@ -14,6 +14,9 @@ from . import engine as E
 _DT = {"fp32": E.DTYPE_F32, "f32": E.DTYPE_F32, "float32": E.DTYPE_F32, "bf16": E.DTYPE_BF16, "bfloat16": E.DTYPE_BF16}
 
 
+_NO_FUSED_LOSS = __import__("os").environ.get("UNET_NO_FUSED_LOSS") is not None   # experiment switch: forward and loss as two engine calls
+
+
 def _stream_ptr(device):
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -279,8 +282,7 @@ class UNet3d:
         x = self._check_input(x)
         plan = self.plan_for(x.shape[2:])
         ws = self._workspace(plan)
-        outs = self._run_forward(plan, ws, x, mode=1)
-        losses, gouts = self.loss(outs, target, cost_ce, cost_dice, cost_mse, collapse_before, plan=plan)
+        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before)
         op_hi, elem_hi = 1 << 30, int(self.flat_grads.numel())
         for op_lo, elem_lo in plan.backward_buckets(max_buckets):
             self._run_backward_part(plan, ws, gouts, op_hi, op_lo)
@@ -317,10 +319,38 @@ class UNet3d:
         x = self._check_input(x)
         plan = self.plan_for(x.shape[2:])
         ws = self._workspace(plan)
-        outs = self._run_forward(plan, ws, x, mode=1)
-        losses, gouts = self.loss(outs, target, cost_ce, cost_dice, cost_mse, collapse_before, plan=plan)
+        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before)
         self._run_backward(plan, ws, gouts)
         return losses
+
+    def _loss_scratch(self, plan):
+        key = ("loss", plan.size, threading.get_ident())
+        sc = self._workspaces.get(key)
+        if sc is None:
+            sc = torch.empty(plan.loss_scratch_bytes, dtype=torch.uint8, device=self._device)
+            self._workspaces[key] = sc
+        return sc
+
+    def _run_forward_loss(self, plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before):
+        """train-mode forward + calc_losses over all levels in ONE engine call (unet_forward_loss): same numbers as forward() then
+        loss(), with the coarse levels' loss kernels issued beside the rest of the decoder."""
+        if target.dtype != torch.int64 or target.device != self._device:
+            raise E.UNetError("target must be an int64 tensor on the model's device")
+        target = target.contiguous()
+        if any(s[1] == 0 for s in plan.output_shapes) or _NO_FUSED_LOSS:   # a level without a head: the two-call path reports it (train.cpp:664-671)
+            outs = self._run_forward(plan, ws, x, mode=1)
+            losses, gouts = self.loss(outs, target, cost_ce, cost_dice, cost_mse, collapse_before, plan=plan)
+            return outs, losses, gouts
+        outs = [torch.empty(s, dtype=torch.float32, device=self._device) for s in plan.output_shapes]
+        gouts = [torch.empty_like(o) for o in outs]
+        losses = torch.empty(4, dtype=torch.float32, device=self._device)
+        mask = (1 if cost_ce else 0) | (2 if cost_dice else 0) | (4 if cost_mse else 0)
+        E.check(E.lib.unet_forward_loss(plan.handle, self._pp, self._bp, x.data_ptr(), E.ptr_array([o.data_ptr() for o in outs]),
+                                        target.data_ptr(), mask, collapse_before, E.ptr_array([g.data_ptr() for g in gouts]),
+                                        losses.data_ptr(), self._loss_scratch(plan).data_ptr(), ws.data_ptr(), _stream_ptr(self._device)))
+        if self._buffers:
+            self.num_batches_tracked += 1
+        return outs, losses, gouts
 
     def loss(self, outs, target, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0, want_grad=True, plan=None):
         """calc_losses + deep-supervision weighting (train.cpp:501-552,634-706) -> (losses[4], dL/d(outs))."""
@@ -329,11 +359,7 @@ class UNet3d:
         if target.dtype != torch.int64 or target.device != self._device:
             raise E.UNetError("target must be an int64 tensor on the model's device")
         target = target.contiguous()
-        key = ("loss", plan.size, threading.get_ident())
-        sc = self._workspaces.get(key)
-        if sc is None:
-            sc = torch.empty(plan.loss_scratch_bytes, dtype=torch.uint8, device=self._device)
-            self._workspaces[key] = sc
+        sc = self._loss_scratch(plan)
         gouts = [torch.empty_like(o) if (o is not None and want_grad) else None for o in outs]
         losses = torch.empty(4, dtype=torch.float32, device=self._device)
         mask = (1 if cost_ce else 0) | (2 if cost_dice else 0) | (4 if cost_mse else 0)
