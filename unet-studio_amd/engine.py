@@ -126,6 +126,7 @@ class Plan:
 
     def __init__(self, arch, in_c, out_c, size, dtype=DTYPE_BF16, device=0, impl=IMPL_AUTO):
         self.handle = C.c_void_p()
+        self._pid = os.getpid()
         D, H, W = size
         check(lib.unet_plan_create(arch.encode(), in_c, out_c, D, H, W, dtype, device, impl, C.byref(self.handle)))
         self.arch, self.in_c, self.out_c, self.size, self.dtype, self.device = arch, in_c, out_c, (D, H, W), dtype, device
@@ -194,7 +195,10 @@ class Plan:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h is not None and h.value and lib is not None:   # `lib` is None once the interpreter tears the module down
+        # `lib` is None once the interpreter tears the module down.  A forked child (multiprocessing.Manager, a DataLoader worker)
+        # inherits the object but must not touch the parent's GPU state: HIP is not fork-safe, and a garbage collection in such a
+        # child used to end in hipFree / hipStreamDestroy there (segmentation fault in the Manager process of the GPU dist tests).
+        if h is not None and h.value and lib is not None and getattr(self, "_pid", None) == os.getpid():
             lib.unet_plan_destroy(h)
             self.handle = C.c_void_p()
 
@@ -231,6 +235,7 @@ class Comm:
 
     def __init__(self, rank, world, id_bytes, device=0):
         self.handle = C.c_void_p()
+        self._pid = os.getpid()
         buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
         check(lib.unet_comm_create(rank, world, buf, device, C.byref(self.handle)))
         self.rank, self.world, self.device = rank, world, device
@@ -265,6 +270,6 @@ class Comm:
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h is not None and h.value and lib is not None:
+        if h is not None and h.value and lib is not None and getattr(self, "_pid", None) == os.getpid():   # never from a forked child
             lib.unet_comm_destroy(h)
             self.handle = C.c_void_p()
