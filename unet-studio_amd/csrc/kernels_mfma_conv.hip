@@ -992,7 +992,9 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
                     asm volatile("ds_write_b128 %0, %1" :: "v"(dl), "v"(Rc[it]) : "memory");
                     if (!(zin && ((umask >> it) & 1u))) *(bf16x8*)d = zero8;   // LDS operations of a wave execute in order
                 }
-            prefetch(pz + 2, Rc);   // always (past the segment's end it reads a valid plane that is never used): a fixed count of loads per step
+            // always, for a fixed count of loads per step; past the segment's last input plane (ze) the load is repeated on plane ze,
+            // which this block has just read (an L2 hit, never used) instead of fetching two more planes from HBM per segment
+            prefetch(pz + 2 <= ze ? pz + 2 : ze, Rc);
             __syncthreads();
         };
         __syncthreads();                       // previous item's planes are no longer read

@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
             const char* ad = ap + ga[it];
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[it]) : "v"(ad) : "memory");
         }
-        const char* bp = bbase + (size_t)((unsigned)bz < (unsigned)g.D ? bz : 0) * bplane_b;
+        // dy planes past the segment are never stored: repeat the segment's last plane (an L2 hit) instead of reading two more from HBM
+        const int bzc = bz < ze ? bz : ze - 1;
+        const char* bp = bbase + (size_t)((unsigned)bzc < (unsigned)g.D ? bzc : 0) * bplane_b;
 #pragma unroll
         for (int it = 0; it < ITERS_B; ++it) {
             const char* ad = bp + gb[it];
