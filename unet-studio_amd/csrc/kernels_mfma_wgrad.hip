@@ -256,21 +256,25 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
         }
     }
 
+    // Slab tile of a (ca, cb) pair in the gradient's layout [cb][ca][t]: a cb row is 16*T contiguous floats.  A lane owns cb = il and
+    // ca = gq*4 .. +3 (16-B pieces 4*T*4 B apart): stored from the registers, every wave instruction touched 64 different lines.  The
+    // tile goes through LDS (row pitch 16*T + 4 floats: at most 2-way conflicts) and leaves as whole rows.
+    constexpr int RP = 16 * T + 4, ROW4 = 4 * T;      // row pitch (floats), float4 per row
     if constexpr (TS) {
-        // every wave holds finished taps: gather [t][lane][4] in LDS, then each lane's run [r][t] (4*T floats, contiguous in the
-        // slab's gradient layout) goes out as 16-B stores
+        // every wave holds finished taps (wave w: taps w, w+4, ...)
         __syncthreads();
-        float* tl = (float*)smem;
+        float* stg = (float*)smem;
 #pragma unroll
         for (int i = 0; i < TW; ++i)
-            if (wave + 4 * i < T) *(f32x4*)(tl + ((wave + 4 * i) * 64 + lane) * 4) = acc[i];
-        __syncthreads();
-        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout + (((size_t)coB * 16 + il) * g.Cin + (size_t)ciB * 16 + gq * 4) * T;
-        for (int e = wave; e < T; e += 4) {
-            f32x4 v;
+            if (wave + 4 * i < T) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = tl[(((4 * e + k) % T) * 64 + lane) * 4 + (4 * e + k) / T];
-            *(f32x4*)(sl + 4 * e) = v;
+                for (int r = 0; r < 4; ++r) stg[il * RP + (gq * 4 + r) * T + wave + 4 * i] = acc[i][r];
+            }
+        __syncthreads();
+        float* base = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout + ((size_t)coB * 16 * g.Cin + (size_t)ciB * 16) * T;
+        for (int q = tid; q < 16 * ROW4; q += 256) {
+            const int row = q / ROW4, c4 = q % ROW4;
+            *(f32x4*)(base + (size_t)row * g.Cin * T + c4 * 4) = *(const f32x4*)(stg + row * RP + c4 * 4);
         }
     }
     if constexpr (!TS) {
@@ -294,17 +298,25 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
         __syncthreads();
     }
     // The slab has the gradient's own layout [cb][ca][t] (torch: [Cout][Cin][k^3], conv_trans [Cin][Cout][8]), so the reduce
-    // kernel is a linear, coalesced sum (the [t][ca][cb] slab of the first version made it a 4-byte read-modify-write
-    // scatter).  A lane owns cb = il and ca = gq*4 .. +3: its 4*T values are one contiguous, 16-B aligned run.
-    if (kw == 0) {
-        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout +
-                    (((size_t)(coB + jt) * 16 + il) * g.Cin + (size_t)(ciB + it_) * 16 + gq * 4) * T;
+    // kernel is a linear, coalesced sum; pair by pair the tile is transposed through LDS and stored as whole rows (see above).
+    {
+        float* stg = (float*)smem;
+#pragma unroll 1
+        for (int pr = 0; pr < P; ++pr) {
+            __syncthreads();
+            if (kw == 0 && pw == pr) {
 #pragma unroll
-        for (int e = 0; e < T; ++e) {   // elements 4e .. 4e+3 of the run [r][t]
-            f32x4 v;
+                for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = acc[(4 * e + k) % T][(4 * e + k) / T];
-            *(f32x4*)(sl + 4 * e) = v;
+                    for (int r = 0; r < 4; ++r) stg[il * RP + (gq * 4 + r) * T + t] = acc[t][r];
+            }
+            __syncthreads();
+            float* base = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout +
+                          ((size_t)(coB + pr % PJ) * 16 * g.Cin + (size_t)(ciB + pr / PJ) * 16) * T;
+            for (int q = tid; q < 16 * ROW4; q += 256) {
+                const int row = q / ROW4, c4 = q % ROW4;
+                *(f32x4*)(base + (size_t)row * g.Cin * T + c4 * 4) = *(const f32x4*)(stg + row * RP + c4 * 4);
+            }
         }
     }
     }
@@ -636,7 +648,9 @@ static void launch_wgrad_cfg(const MfmaWgradArgs& a0, const WgradCfg& c, hipStre
     constexpr int HZ = (BZ - 1) * S + KD, HY = (BY - 1) * S + KD, HX = (BX - 1) * S + KD, T = KD * KD * KD;
     constexpr size_t tile_lds = (size_t)PI * HZ * HY * HX * 32 + (size_t)PJ * BZ * BY * BX * 32;
     constexpr size_t red_lds = PI * PJ < 4 ? (size_t)(PI * PJ) * T * 64 * 16 : 0;   // only K-split waves reduce through LDS
-    constexpr size_t lds = tile_lds > red_lds ? (tile_lds > 8192 ? tile_lds : 8192) : red_lds;
+    constexpr size_t stg_lds = (size_t)16 * (16 * T + 4) * 4;   // slab tile staging
+    constexpr size_t lds0 = tile_lds > red_lds ? (tile_lds > 8192 ? tile_lds : 8192) : red_lds;
+    constexpr size_t lds = lds0 > stg_lds ? lds0 : stg_lds;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static std::atomic<uint64_t> attr_done{0};
     set_max_lds_once(attr_done, (const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, (int)lds);

@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
 
     // this block's item: footprint column and z segment (blocks that share an XCD get neighbouring items: shared halos in one L2)
     const int item = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int seg = item % a.nseg, col = item / a.nseg;
+    const int nsegs = a.nseg < 0 ? -a.nseg : a.nseg;
+    const int seg = item % nsegs, col = item / nsegs;
     const int x0 = (col % a.cols_x) * BX, y0 = (col / a.cols_x) * BY;
     const int zs = seg * a.zlen, ze = zs + a.zlen < g.D ? zs + a.zlen : g.D, len = ze - zs;
 
@@ -131,7 +132,10 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
     //   * no VALU instruction touches a prefetch register: it goes from the load straight into ds_write_b128 (both inline
     //     assembly); the bias sums re-read the stored dy units from LDS (LDS operations of a wave execute in order).
     constexpr int NL = ITERS_A + ITERS_B;
-    bf16x8 RA[2][ITERS_A], RB[2][ITERS_B];
+    // PD register sets = planes in flight.  Three where the registers allow it (NL <= 4 loads per step: the multi-pair blocks, whose
+    // steps are short -- 27 KB staged for 0.7 us of MFMAs -- and ran at ~1 TB/s with two); the one-pair block keeps two (5 loads per step).
+    constexpr int PD = NL <= 4 ? 3 : 2;
+    bf16x8 RA[PD][ITERS_A], RB[PD][ITERS_B];
     const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
     auto fetch = [&](auto setc, int pz, int bz) {
         constexpr int SET = decltype(setc)::value;
@@ -154,13 +158,14 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
         }
     };
     // stores set SET: input plane pz (zeros outside the volume), dy plane only when it lies inside the segment (have_b).
-    // younger: the other set's NL loads were issued after this set's and may stay in flight.
-    auto commit = [&](auto setc, char* buf, int pz, bool have_b, bool younger) {
+    // younger: how many fetches (NL loads each) were issued after this set's and may stay in flight.
+    auto commit = [&](auto setc, char* buf, int pz, bool have_b, int younger) {
         constexpr int SET = decltype(setc)::value;
         auto& ra = RA[SET];
         auto& rb = RB[SET];
         const bool zin = (unsigned)pz < (unsigned)g.D;
-        if (younger) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL) : "memory");
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NL) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NL) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -246,33 +251,48 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
     const std::integral_constant<int, 0> c0;
     const std::integral_constant<int, 1> c1;
     const std::integral_constant<int, 2> c2;
+    // plane k (input zs-1+k, dy zs+k) travels in register set k % PD; step n stores plane n+1 and requests plane n+PD
     fetch(c0, zs - 1, zs);
-    commit(c0, smem, zs - 1, len > 0, false);
+    commit(c0, smem, zs - 1, len > 0, 0);
     fetch(c1, zs, zs + 1);
+    if constexpr (PD == 3) fetch(c2, zs + 1, zs + 2);
     __syncthreads();
-    auto step = [&](auto ph, auto setc, int n) {
-        constexpr int SET = decltype(setc)::value;           // holds plane n+1 (input zs+n, dy zs+n+1); the other set is free
+    auto step = [&](auto ph, auto set_commit, auto set_fetch, int n) {
         char* cur = smem + (n & 1) * BUF;
         char* nxt = smem + ((n + 1) & 1) * BUF;
-        const bool more = n <= len;                          // another step follows
-        const bool ahead = n + 1 <= len;                     // plane n+2 is used by step n+2
-        if (ahead) fetch(std::integral_constant<int, 1 - SET>{}, zs + n + 1, zs + n + 2);
+        const bool more = n <= len;                          // another step follows: plane n+1 is needed
+        const bool ahead = n + PD <= len + 1;                // plane n+PD is used by step n+PD
+        if (ahead) fetch(set_fetch, zs - 1 + n + PD, zs + n + PD);
         compute(ph, cur, n < len);
-        if (more) commit(setc, nxt, zs + n, n + 1 < len, ahead);
+        // fetches younger than plane n+1's: planes n+2 .. n+PD as far as they were requested (plane k exists for k <= len+1)
+        int younger = len + 1 - (n + 1);
+        if (younger > PD - 1) younger = PD - 1;
+        if (younger < 0) younger = 0;
+        if (more) commit(set_commit, nxt, zs + n, n + 1 < len, younger);
         __syncthreads();
     };
-    for (int n = 0; n <= len + 1; n += 6) {
-        step(c0, c1, n);
-        if (n + 1 > len + 1) break;
-        step(c1, c0, n + 1);
-        if (n + 2 > len + 1) break;
-        step(c2, c1, n + 2);
-        if (n + 3 > len + 1) break;
-        step(c0, c0, n + 3);
-        if (n + 4 > len + 1) break;
-        step(c1, c1, n + 4);
-        if (n + 5 > len + 1) break;
-        step(c2, c0, n + 5);
+    if constexpr (PD == 2) {
+        for (int n = 0; n <= len + 1; n += 6) {          // 3 dy slots x 2 sets
+            step(c0, c1, c0, n);
+            if (n + 1 > len + 1) break;
+            step(c1, c0, c1, n + 1);
+            if (n + 2 > len + 1) break;
+            step(c2, c1, c0, n + 2);
+            if (n + 3 > len + 1) break;
+            step(c0, c0, c1, n + 3);
+            if (n + 4 > len + 1) break;
+            step(c1, c1, c0, n + 4);
+            if (n + 5 > len + 1) break;
+            step(c2, c0, c1, n + 5);
+        }
+    } else {
+        for (int n = 0; n <= len + 1; n += 3) {          // 3 dy slots = 3 sets: plane n+1 sits in set (n+1) % 3, plane n+3 goes to set n % 3
+            step(c0, c1, c0, n);
+            if (n + 1 > len + 1) break;
+            step(c1, c2, c1, n + 1);
+            if (n + 2 > len + 1) break;
+            step(c2, c0, c2, n + 2);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the epilogue reuses the prefetch registers
 
@@ -302,16 +322,32 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
             }
         }
     }
-    // slab layout = the gradient's own layout [cb][ca][t]: a lane owns cb = il and ca = gq*4 .. +3 -> 4*T contiguous floats
-    if (kw == 0) {
-        float* sl = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout +
-                    (((size_t)(cbB + ib) * 16 + il) * g.Cin + (size_t)(caB + ia) * 16 + gq * 4) * T;
+    // Slab layout = the gradient's own layout [cb][ca][t]: for one (ca, cb) tile pair a cb row is 16*27 contiguous floats (1728 B).
+    // A lane owns cb = il and ca = gq*4 .. +3, i.e. 16-B pieces 432 B apart -- stored straight from the registers, every wave
+    // instruction touched 64 different lines (27 KB per pair in 1728 scattered pieces: ~10 us of a 2x2-pair block's life).  The
+    // pair's tile is therefore transposed through LDS (row pitch 436 floats: 2-way conflicts at most) and leaves as whole rows.
+    {
+        constexpr int RP = 436;
+        static_assert(16 * RP * 4 <= LDS_BYTES, "slab staging");
+        float* stg = (float*)smem;
+        const bool store = a.nseg >= 0;
+#pragma unroll 1
+        for (int pr = 0; pr < P; ++pr) {
+            __syncthreads();
+            if (kw == 0 && pw == pr) {
 #pragma unroll
-        for (int e = 0; e < T; ++e) {
-            f32x4 v;
+                for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = acc[(4 * e + k) % T][(4 * e + k) / T];
-            *(f32x4*)(sl + 4 * e) = v;
+                    for (int r = 0; r < 4; ++r) stg[il * RP + (gq * 4 + r) * T + t] = acc[t][r];
+            }
+            __syncthreads();
+            float* base = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout +
+                          ((size_t)(cbB + pr % PB) * 16 * g.Cin + (size_t)(caB + pr / PB) * 16) * T;
+            if (store)
+                for (int q = tid; q < 16 * 108; q += NT) {
+                    const int row = q / 108, c4 = q % 108;
+                    *(f32x4*)(base + (size_t)row * g.Cin * T + c4 * 4) = *(const f32x4*)(stg + row * RP + c4 * 4);
+                }
         }
     }
     if (do_bias) {
@@ -405,6 +441,8 @@ int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const v
     a.slab = (float*)scratch;
     a.bias_slab = want_bias ? a.slab + (size_t)c.gx * 27 * g.Cin * g.Cout : nullptr;
     a.cols_x = c.cols_x; a.cols_y = c.cols_y; a.nseg = c.nseg; a.zlen = c.zlen;
+    static const bool noslab = getenv("UNET_WZ_NOSLAB") != nullptr;   // timing experiment only (results are wrong): skip the slab stores
+    if (noslab) a.nseg = -c.nseg;
     if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s);
     else if (c.pa == 2) launch_wz<32, 4, 2, 1>(a, c, s);
     else if (c.pb == 2) launch_wz<32, 4, 1, 2>(a, c, s);

@@ -157,13 +157,18 @@ def main(which, path, out_json=None):
             if any(st["hand_waits"].get(k, 0) != 2 for k in (3, 5, 7)):
                 errors.append("hand-placed waits vmcnt(3/5/7): %s (expected 2 each)" % st["hand_waits"])
         else:
-            # 8 fetch sites (2 prologue + 6 steps), NL loads each; 7 commit sites with a vmcnt(NL) / vmcnt(0) pair (prologue: vmcnt(0) only)
-            if st["asm_loads"] % 8:
-                errors.append("inline-asm loads: %d (expected 8 fetch sites x NL)" % st["asm_loads"])
-            nl = st["asm_loads"] // 8
+            # PD = 2 sets: 8 fetch sites (2 prologue + 6 unrolled steps); PD = 3: 6 sites (3 + 3).  Every hand-placed wait is
+            # vmcnt(0), vmcnt(NL) or vmcnt(2 NL) with NL = loads per fetch.
+            import math
             w = st["hand_waits"]
-            if w.get(nl, 0) != 6 or w.get(0, 0) != 8 or set(w) - {0, nl}:
-                errors.append("hand-placed waits: %s (expected 6 x vmcnt(%d), 8 x vmcnt(0))" % (w, nl))
+            nz = [k for k in w if k]
+            nl = 0
+            for k in nz:
+                nl = math.gcd(nl, k)
+            if not nl or st["asm_loads"] % nl or st["asm_loads"] // nl not in (6, 8):
+                errors.append("inline-asm loads: %d with waits %s (expected 6 or 8 fetch sites x NL)" % (st["asm_loads"], w))
+            elif set(w) - {0, nl, 2 * nl} or not w.get(0) or not w.get(nl):
+                errors.append("hand-placed waits: %s (expected only vmcnt(0), vmcnt(%d), vmcnt(%d))" % (w, nl, 2 * nl))
         rec = dict(kernel=sym, ok=not errors, errors=errors, vgpr_count=meta.get(".vgpr_count"), **st)
         recs.append(rec)
         failed = failed or bool(errors)
