@@ -321,16 +321,27 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
     }
     }
     if (do_bias) {
-        // threads with equal ub hold partial sums of the same 8 channels: reduce over the 256/GB of them
-        __syncthreads();
-        float* bred = (float*)smem;   // [256][8]
+        // threads with equal tid % GB hold partial sums of the same 8 channels: shuffle tree inside each wave (lanes GB apart), then the
+        // four wave totals through LDS (the serial loop over 256 / GB LDS values per output cost ~6 us at the end of every block)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bred[tid * 8 + e] = bsum[e];
+        for (int e = 0; e < 8; ++e) {
+            float v = bsum[e];
+#pragma unroll
+            for (int m = GB; m < 64; m <<= 1) v += __shfl_xor(v, m);
+            bsum[e] = v;
+        }
+        __syncthreads();
+        float* bred = (float*)smem;   // [4 waves][GB][8]
+        if (lane < GB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bred[(wave * GB + lane) * 8 + e] = bsum[e];
+        }
         __syncthreads();
         if (tid < GB * 8) {
             int u = tid / 8, e = tid % 8;
             float sacc = 0.f;
-            for (int k = u; k < 256; k += GB) sacc += bred[k * 8 + e];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) sacc += bred[(w * GB + u) * 8 + e];
             int c = (coB + (u >> 1)) * 16 + (u & 1) * 8 + e;
             a.bias_slab[(size_t)blockIdx.x * g.Cout + c] = sacc;
         }

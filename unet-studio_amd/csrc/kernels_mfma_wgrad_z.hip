@@ -351,16 +351,27 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
         }
     }
     if (do_bias) {
-        __syncthreads();
-        float* bred = (float*)smem;   // [NT][8]
-        static_assert(NT * 8 * 4 <= LDS_BYTES, "bias scratch");
+        // threads with equal tid % GB hold partial sums of the same 8 channels: shuffle tree inside each wave (lanes GB apart), then
+        // the NW wave totals through LDS.  (A serial loop of NT / GB LDS reads per output here cost ~6 us at the end of every block.)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bred[tid * 8 + e] = bsum[e];
+        for (int e = 0; e < 8; ++e) {
+            float v = bsum[e];
+#pragma unroll
+            for (int m = GB; m < 64; m <<= 1) v += __shfl_xor(v, m);
+            bsum[e] = v;
+        }
+        __syncthreads();
+        float* bred = (float*)smem;   // [NW][GB][8]
+        if (lane < GB) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bred[(wave * GB + lane) * 8 + e] = bsum[e];
+        }
         __syncthreads();
         if (tid < GB * 8) {
             const int u = tid / 8, e = tid % 8;
             float sacc = 0.f;
-            for (int k = u; k < NT; k += GB) sacc += bred[k * 8 + e];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sacc += bred[(w * GB + u) * 8 + e];
             a.bias_slab[(size_t)blockIdx.x * g.Cout + (cbB + (u >> 1)) * 16 + (u & 1) * 8 + e] = sacc;
         }
     }
