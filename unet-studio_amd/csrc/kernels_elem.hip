@@ -151,11 +151,37 @@ __global__ void __launch_bounds__(256) k_norm_bwd_stats8(const uint4* __restrict
             }
         }
     }
+    // threads with equal tid % G8 hold sums of the same 8 channels.  G8 <= 32: shuffle tree over the lanes G8 apart, then the four
+    // wave totals through LDS (the serial loop over NV = 256 / G8 LDS rows per output -- 128 at 16 channels -- was as long as the
+    // block's whole voxel loop).  G8 = 64..256: a wave holds each group at most once, the (<= 4) rows are summed from LDS as before.
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (G8 <= 32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = s1[e], b = s2[e];
+            for (int m = G8; m < 64; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+            s1[e] = a; s2[e] = b;
+        }
+        if (ln < G8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[wv * G8 + ln][e] = s1[e]; red[wv * G8 + ln][8 + e] = s2[e]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < G8 * 8) {
+            const int gg = threadIdx.x / 8, e = threadIdx.x % 8;
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[w * G8 + gg][e]; b += red[w * G8 + gg][8 + e]; }
+            partial[((int64_t)blockIdx.x * C + gg * 8 + e) * 2 + 0] = a;
+            partial[((int64_t)blockIdx.x * C + gg * 8 + e) * 2 + 1] = b;
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
     __syncthreads();
-    if (threadIdx.x < G8 * 8) {
-        const int gg = threadIdx.x / 8, e = threadIdx.x % 8;
+    for (int o = threadIdx.x; o < G8 * 8; o += 256) {
+        const int gg = o / 8, e = o % 8;
         float a = 0.f, b = 0.f;
         for (int l = 0; l < NV; ++l) { a += red[l * G8 + gg][e]; b += red[l * G8 + gg][8 + e]; }
         partial[((int64_t)blockIdx.x * C + gg * 8 + e) * 2 + 0] = a;
@@ -206,11 +232,33 @@ __global__ void __launch_bounds__(256) k_colsum8(const uint4* __restrict__ x8, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) s1[e] += f[e];
     }
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (G8 <= 32) {      // as in k_norm_bwd_stats8: shuffle tree over the lanes G8 apart, then the four wave totals
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = s1[e];
+            for (int m = G8; m < 64; m <<= 1) a += __shfl_xor(a, m);
+            s1[e] = a;
+        }
+        if (ln < G8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wv * G8 + ln][e] = s1[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < G8 * 8) {
+            const int gg = threadIdx.x / 8, e = threadIdx.x % 8;
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += red[w * G8 + gg][e];
+            partial[(int64_t)blockIdx.x * C + gg * 8 + e] = a;
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s1[e];
     __syncthreads();
-    if (threadIdx.x < G8 * 8) {
-        const int gg = threadIdx.x / 8, e = threadIdx.x % 8;
+    for (int o = threadIdx.x; o < G8 * 8; o += 256) {
+        const int gg = o / 8, e = o % 8;
         float a = 0.f;
         for (int l = 0; l < NV; ++l) a += red[l * G8 + gg][e];
         partial[(int64_t)blockIdx.x * C + gg * 8 + e] = a;
