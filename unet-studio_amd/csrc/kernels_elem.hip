@@ -522,7 +522,45 @@ __global__ void __launch_bounds__(256) k_apply_view8(SrcDesc src, uint4* __restr
     }
     out[i] = make_uint4(w[0], w[1], w[2], w[3]);
 }
+// the same copy in the geometry of k_norm_bwd_apply8 (a thread keeps its 8 channels' scale / shift in registers and walks voxels,
+// four 16-B loads in flight): 134 MB in 32 us (one unit per thread, 16 coefficient loads each) -> see profiles/tools/elem_bench.cpp
+__global__ void __launch_bounds__(256) k_apply_view8g(SrcDesc src, uint4* __restrict__ out, int64_t S, int64_t VPB) {
+    const int G8 = src.C / 8, NV = 256 / G8, grp = threadIdx.x % G8, lane = threadIdx.x / G8, c0 = grp * 8;
+    const int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
+    const uint4* in = (const uint4*)src.ptr;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = src.scale ? src.scale[c0 + e] : 1.f; sh[e] = src.scale ? src.shift[c0 + e] : 0.f; }
+    const int act = src.act;
+    auto one = [&](uint4 v) {
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float lo = act_f(fmaf(__uint_as_float(w[e] << 16), sc[2 * e], sh[2 * e]), act);
+            float hi = act_f(fmaf(__uint_as_float(w[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), act);
+            w[e] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(lo)) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(hi)) << 16);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    int64_t v = v0 + lane;
+    for (; v + 3 * NV < v1; v += 4 * NV) {
+        uint4 r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = in[(v + j * NV) * G8 + grp];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(v + j * NV) * G8 + grp] = one(r[j]);
+    }
+    for (; v < v1; v += NV) out[v * G8 + grp] = one(in[v * G8 + grp]);
+}
 void launch_apply_view(int dtype, SrcDesc src, void* out, int64_t S, hipStream_t s) {
+    if (dtype == 1 && src.C % 8 == 0 && src.C <= 2048 && 256 % (src.C / 8) == 0 && S * src.C >= (1 << 18)) {
+        int64_t vpb = (S + 4095) / 4096;
+        const int64_t nv4 = 4 * (256 / (src.C / 8));
+        if (vpb < nv4) vpb = nv4;
+        vpb = (vpb + nv4 - 1) / nv4 * nv4;           // whole trips of four units per thread
+        k_apply_view8g<<<cdiv64(S, vpb), 256, 0, s>>>(src, (uint4*)out, S, vpb);
+        return;
+    }
     if (dtype == 1 && src.C % 8 == 0) {
         int64_t n8 = S * src.C / 8;
         k_apply_view8<<<cdiv64(n8, 256), 256, 0, s>>>(src, (uint4*)out, n8);
@@ -691,8 +729,80 @@ __global__ void __launch_bounds__(256) k_loss_partial_reg(const float* __restric
     if ((int)threadIdx.x < np)
         partial[(int64_t)blockIdx.x * np + threadIdx.x] = red[threadIdx.x] + red[RS + threadIdx.x] + red[2 * RS + threadIdx.x] + red[3 * RS + threadIdx.x];
 }
+// no class merging, <= 8 classes, S % 4 == 0 (every level of the default training set-up): four consecutive voxels per thread and
+// trip -- one 16-B load per class plane and two for the int64 targets instead of 4-B / 8-B ones (67 MB in 22 us -> see
+// profiles/tools/elem_bench.cpp); the same per-thread register accumulators and fixed-order block reduction
+template <int OCMAX>
+__global__ void __launch_bounds__(256) k_loss_partial_v4(const float* __restrict__ logits, const int64_t* __restrict__ target, int C,
+                                                         int64_t S, float* __restrict__ partial) {
+    constexpr int RS = 3 + 2 * OCMAX + 1;
+    __shared__ float red[4 * RS];
+    const int oc = C, np = 3 + 2 * oc;
+    float ce = 0.f, mse = 0.f, nv = 0.f, inter[OCMAX], card[OCMAX];
+#pragma unroll
+    for (int c = 0; c < OCMAX; ++c) { inter[c] = 0.f; card[c] = 0.f; }
+    const int64_t S4 = S >> 2;
+    for (int64_t q4 = (int64_t)blockIdx.x * 256 + threadIdx.x; q4 < S4; q4 += (int64_t)gridDim.x * 256) {
+        const longlong2 t01 = ((const longlong2*)target)[2 * q4], t23 = ((const longlong2*)target)[2 * q4 + 1];
+        const int64_t tv[4] = {t01.x, t01.y, t23.x, t23.y};
+        float4 pl[OCMAX];
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c)
+            pl[c] = c < oc ? ((const float4*)(logits + (int64_t)c * S))[q4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t t = tv[j];
+            if (!(t < C)) continue;
+            const int tt = (int)t;
+            float lg[OCMAX], mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < OCMAX; ++c) { lg[c] = j == 0 ? pl[c].x : j == 1 ? pl[c].y : j == 2 ? pl[c].z : pl[c].w; mx = fmaxf(mx, lg[c]); }
+            float sum = 0.f, lt = 0.f;
+#pragma unroll
+            for (int c = 0; c < OCMAX; ++c) { if (c == tt) lt = lg[c]; lg[c] = c < oc ? __expf(lg[c] - mx) : 0.f; sum += lg[c]; }
+            const float inv = 1.f / sum;
+            float psq = 0.f, pt = 0.f;
+#pragma unroll
+            for (int c = 0; c < OCMAX; ++c) {
+                if (c < oc) {
+                    const float p = clamp_p(lg[c] * inv);
+                    psq = fmaf(p, p, psq);
+                    const bool hit = c == tt;
+                    if (hit) { pt = p; inter[c] += p; }
+                    card[c] += p + (hit ? 1.f : 0.f);
+                }
+            }
+            ce += -(lt - mx - __logf(sum));
+            mse += psq - 2.f * pt + 1.f;
+            nv += 1.f;
+        }
+    }
+    auto wsum = [](float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w3[3] = {wsum(ce), wsum(mse), wsum(nv)};
+    if (lane == 0) { red[wave * RS + 0] = w3[0]; red[wave * RS + 1] = w3[1]; red[wave * RS + 2] = w3[2]; }
+#pragma unroll
+    for (int c = 0; c < OCMAX; ++c) {
+        if (c < oc) {
+            const float a = wsum(inter[c]), b = wsum(card[c]);
+            if (lane == 0) { red[wave * RS + 3 + c] = a; red[wave * RS + 3 + oc + c] = b; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < np)
+        partial[(int64_t)blockIdx.x * np + threadIdx.x] = red[threadIdx.x] + red[RS + threadIdx.x] + red[2 * RS + threadIdx.x] + red[3 * RS + threadIdx.x];
+}
+static inline bool loss_v4_ok(const void* a, const void* b, const void* c, int C, int64_t S, int collapse) {
+    return !collapse && C <= 8 && S % 4 == 0 && S >= 4096 && ((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) % 16 == 0;
+}
 void launch_loss_partial(const float* logits, const int64_t* target, int C, int64_t S, int collapse, float* partial, hipStream_t s) {
     int oc = collapse ? C - collapse + 1 : C;
+    if (loss_v4_ok(logits, target, nullptr, C, S, collapse)) {
+        // loss_blocks(S) rows are summed by the finalize: every one of them is written (S/4 >= 256 * blocks for S >= 2^20; smaller
+        // levels: blocks without a voxel write zeros)
+        k_loss_partial_v4<8><<<loss_blocks(S), 256, 0, s>>>(logits, target, C, S, partial);
+        return;
+    }
     if (oc <= 8) k_loss_partial_reg<8><<<loss_blocks(S), 256, 0, s>>>(logits, target, C, S, collapse, partial);
     else if (oc <= 32) k_loss_partial_reg<32><<<loss_blocks(S), 256, 0, s>>>(logits, target, C, S, collapse, partial);
     else k_loss_partial<<<loss_blocks(S), 256, (3 + 2 * oc) * sizeof(float), s>>>(logits, target, C, S, collapse, partial);
@@ -700,14 +810,14 @@ void launch_loss_partial(const float* logits, const int64_t* target, int C, int6
 
 // level_out: [0] ce [1] dice [2] mse [3] n  [4 .. 4+oc) inter  [4+oc .. 4+2oc) card
 // totals: [0] total loss (accumulated over levels) [1..3] level-0 ce, dice, mse
-__global__ void __launch_bounds__(256) k_loss_finalize(const float* __restrict__ partial, int nblk, int oc, float weight, int cost_mask,
+__global__ void __launch_bounds__(1024) k_loss_finalize(const float* __restrict__ partial, int nblk, int oc, float weight, int cost_mask,
                                                        float* level_out, float* totals, int set_stats) {
     extern __shared__ double shd[];  // 3 + 2*oc
     int np = 3 + 2 * oc;
     // one wave per value, 64 row lanes (<= 16 rows each at 1024 blocks), shuffle tree: fixed order.  (16 values x 16 split lanes with
     // 64 dependent 4-byte loads per thread took 18 us at the two largest levels.)
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    for (int i = wv; i < np; i += 4) {
+    for (int i = wv; i < np; i += (int)(blockDim.x >> 6)) {
         double a = 0.0;
         for (int b = ln; b < nblk; b += 64) a += partial[(int64_t)b * np + i];
         for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
@@ -730,7 +840,7 @@ __global__ void __launch_bounds__(256) k_loss_finalize(const float* __restrict__
 }
 void launch_loss_finalize(const float* partial, int nblk, int oc, float weight, int cost_mask, float* level_out, float* totals,
                           int set_stats, hipStream_t s) {
-    k_loss_finalize<<<1, 256, (3 + 2 * oc) * sizeof(double), s>>>(partial, nblk, oc, weight, cost_mask, level_out, totals, set_stats);
+    k_loss_finalize<<<1, 3 + 2 * oc > 8 ? 1024 : 512, (3 + 2 * oc) * sizeof(double), s>>>(partial, nblk, oc, weight, cost_mask, level_out, totals, set_stats);
 }
 
 __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ logits, const int64_t* __restrict__ target, int C, int64_t S,
@@ -791,8 +901,76 @@ __global__ void __launch_bounds__(256) k_loss_grad(const float* __restrict__ log
         for (int c = 0; c < k; ++c) dlogits[(int64_t)c * S + v] = d0 * __expf(logits[(int64_t)c * S + v] - m0) / s0;
     }
 }
+// four consecutive voxels per thread (see k_loss_partial_v4): 16-B loads and stores per class plane, the per-class dice terms
+// computed once per thread; per voxel the same expressions in the same order as k_loss_grad (bit-identical gradients)
+template <int OCMAX>
+__global__ void __launch_bounds__(256) k_loss_grad_v4(const float* __restrict__ logits, const int64_t* __restrict__ target, int C, int64_t S,
+                                                      const float* __restrict__ level_out, float weight, int cost_mask,
+                                                      float* __restrict__ dlogits) {
+    const int oc = C;
+    const int64_t q4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q4 >= (S >> 2)) return;
+    const float w_ce = (!(cost_mask & 7) || (cost_mask & 1)) ? weight : 0.f;
+    const float w_dice = (cost_mask & 2) ? weight : 0.f, w_mse = (cost_mask & 4) ? weight : 0.f;
+    const float n = level_out[3];
+    const float dden = (float)(oc - 1 > 1 ? oc - 1 : 1), eps = 1e-5f;
+    float dice_hit[OCMAX], dice_miss[OCMAX];
+#pragma unroll
+    for (int c = 0; c < OCMAX; ++c) {
+        dice_hit[c] = dice_miss[c] = 0.f;
+        if (c >= 1 && c < oc) {
+            const float den = level_out[4 + oc + c] + eps, in2 = 2.f * level_out[4 + c] + eps;
+            dice_hit[c] = w_dice * (-(2.f * 1.f * den - in2) / (den * den)) / dden;
+            dice_miss[c] = w_dice * (-(2.f * 0.f * den - in2) / (den * den)) / dden;
+        }
+    }
+    const longlong2 t01 = ((const longlong2*)target)[2 * q4], t23 = ((const longlong2*)target)[2 * q4 + 1];
+    const int64_t tv[4] = {t01.x, t01.y, t23.x, t23.y};
+    float4 pl[OCMAX];
+#pragma unroll
+    for (int c = 0; c < OCMAX; ++c)
+        pl[c] = c < oc ? ((const float4*)(logits + (int64_t)c * S))[q4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    float out[OCMAX][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t t = tv[j];
+        const bool valid = t < C;
+        const int tt = (int)t;
+        float lg[OCMAX], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c) { lg[c] = j == 0 ? pl[c].x : j == 1 ? pl[c].y : j == 2 ? pl[c].z : pl[c].w; mx = fmaxf(mx, lg[c]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c) { lg[c] = c < oc ? __expf(lg[c] - mx) : 0.f; sum += lg[c]; }
+        const float inv = 1.f / sum;
+        float g[OCMAX], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c) {
+            g[c] = 0.f;
+            if (c < oc) {
+                const float q = lg[c] * inv, p = clamp_p(q);
+                float gg = 0.f;
+                gg += w_mse * (2.f * p - (c == tt ? 2.f : 0.f)) / n;
+                if (c >= 1) gg += c == tt ? dice_hit[c] : dice_miss[c];
+                if (!(q >= 1e-6f && q <= 1.0f - 1e-6f)) gg = 0.f;
+                dot = fmaf(gg, q, dot);
+                g[c] = gg; lg[c] = q;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < OCMAX; ++c)
+            out[c][j] = (c < oc && valid) ? lg[c] * (g[c] - dot) + w_ce * (lg[c] - (c == tt ? 1.f : 0.f)) / n : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < OCMAX; ++c)
+        if (c < oc) ((float4*)(dlogits + (int64_t)c * S))[q4] = make_float4(out[c][0], out[c][1], out[c][2], out[c][3]);
+}
 void launch_loss_grad(const float* logits, const int64_t* target, int C, int64_t S, int collapse, const float* level_out, float weight,
                       int cost_mask, float* dlogits, hipStream_t s) {
+    if (loss_v4_ok(logits, target, dlogits, C, S, collapse)) {
+        k_loss_grad_v4<8><<<cdiv64(S >> 2, 256), 256, 0, s>>>(logits, target, C, S, level_out, weight, cost_mask, dlogits);
+        return;
+    }
     k_loss_grad<<<cdiv64(S, 256), 256, 0, s>>>(logits, target, C, S, collapse, level_out, weight, cost_mask, dlogits);
 }
 
