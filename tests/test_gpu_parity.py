@@ -70,6 +70,9 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     # groups per launch, ragged footprints in y and x, z segments of unequal length, volumes narrower than one 32-voxel row
     (16, 16, (9, 11, 37), 3, 1), (32, 16, (13, 9, 33), 3, 1), (16, 32, (5, 12, 40), 3, 1), (32, 32, (6, 9, 40), 3, 1),
     (64, 32, (8, 8, 24), 3, 1), (48, 16, (4, 10, 70), 3, 1), (16, 16, (40, 8, 32), 3, 1), (32, 64, (11, 5, 29), 3, 1),
+    # sliding window for a single 16-channel chunk (bf16; forward Cin = 16, dgrad Cout = 16; W >= 12, D >= 8): one and two row tiles,
+    # ragged footprints, z segments of unequal length
+    (16, 16, (11, 9, 19), 3, 1), (16, 32, (10, 17, 33), 3, 1), (32, 16, (9, 10, 18), 3, 1), (16, 16, (37, 8, 16), 3, 1),
     # fp32 matrix-core conv (fp32 engine, volumes >= 4096 voxels): NT 1 / 2, ragged tile edges in z, y and x, 8-channel chunk tail
     (16, 16, (16, 16, 32), 3, 1), (32, 64, (17, 19, 21), 3, 1), (24, 48, (9, 23, 22), 3, 1), (64, 32, (18, 17, 16), 3, 1),
 ]
@@ -110,7 +113,8 @@ def test_conv3d_ops(case, dt, impl):
     assert rel(dbd.cpu().numpy() - 1.0, db_ref) < (2e-5 if dt == "fp32" else 1e-2)
 
 
-@pytest.mark.parametrize("case", [(1, 16, (9, 13, 21)), (1, 32, (4, 8, 16)), (32, 16, (6, 9, 20)), (16, 16, (5, 8, 17))])
+@pytest.mark.parametrize("case", [(1, 16, (9, 13, 21)), (1, 32, (4, 8, 16)), (32, 16, (6, 9, 20)), (16, 16, (5, 8, 17)),
+                                  (16, 16, (9, 13, 21)), (16, 32, (12, 9, 20)), (16, 16, (33, 8, 16))])
 def test_conv3d_plain_with_statistics(case):
     """plain input (what a plan feeds its convs: activated copies), bf16, statistics epilogue: the first-conv MFMA kernel
     (Cin = 1) and the persistent kernel"""

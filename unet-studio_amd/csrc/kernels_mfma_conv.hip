@@ -27,22 +27,6 @@
 
 namespace unet {
 
-struct MfmaConvArgs {
-    ConvGeom g;          // GEMM view: Cin = contraction channels, Cout = rows; D,H,W = volume read; Do,Ho,Wo = grid the tiles cover
-    SrcDesc src[2];
-    int nsrc;
-    const void* w;       // packed filter
-    const float* bias;   // nullptr: none (indexed by destination channel)
-    void* out[2];        // channels-last bf16 destinations (split at outC[0] channels)
-    int outC[2];
-    int out_acc[2];
-    int nout;
-    float* stats;        // [nblk][Cout][2] or nullptr
-    int tiles_x, tiles_y, tiles_z;
-    int sc_C;            // SC: destination channels per tap (rows = 8 * sc_C)
-    int oD, oH, oW;      // destination volume
-};
-
 // ---- filter packing: fp32 torch layout -> bf16 fragments [chunk][kstep][row tile][lane][8] ----
 enum PackMode {
     PK_CONV_FWD = 0,    // rows o = cout, k-channel i = cin, T taps:           w[(o*A + i)*T + t]              A = Cin
@@ -55,9 +39,9 @@ enum PackMode {
 // One pack unit = (channel chunk q, row tile nt): the 16 x CK x T filter values are gathered into LDS in the order that is
 // contiguous in the SOURCE (the element-per-thread version read 4 B at a 108-B stride: 0.15 ms per step for 60 MB), then the
 // KSTEPS fragments [lane][8] of the unit are written with 16-B stores.
-constexpr int PACK_LDS_FLOATS = 16 * (32 * 27 + 1);
+constexpr int PACK_LDS_ELEMS = 16 * (32 * 27 + 1);   // bf16: the values are rounded on the way in (27 KB per block: 5 blocks per CU instead of 2)
 template <int CK, int T, int MODE>   // compile-time divisors and mode: with run-time values the index arithmetic set the kernel's time
-__device__ __forceinline__ void pack_unit_t(const float* __restrict__ w, __bf16* __restrict__ out, int unit, int Co, int A, int B, float* lds) {
+__device__ __forceinline__ void pack_unit_t(const float* __restrict__ w, __bf16* __restrict__ out, int unit, int Co, int A, int B, __bf16* lds) {
     constexpr int KSTEPS = CK == 32 ? T : (T + 1) / 2;
     const int NTT = Co / 16;
     const int q = unit / NTT, nt = unit % NTT, o0 = nt * 16;
@@ -102,7 +86,7 @@ __device__ __forceinline__ void pack_unit_t(const float* __restrict__ w, __bf16*
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (dst[u] >= 0) lds[dst[u]] = v[u];
+            if (dst[u] >= 0) lds[dst[u]] = (__bf16)v[u];
     }
     __syncthreads();
     for (int f = threadIdx.x; f < KSTEPS * 64; f += 256) {
@@ -112,12 +96,12 @@ __device__ __forceinline__ void pack_unit_t(const float* __restrict__ w, __bf16*
         else { tap = 2 * ks + (lane >> 5); c0 = 8 * ((lane >> 4) & 1); }
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(tap < T ? lds[row * RS + (c0 + e) * T + tap] : 0.f);
+        for (int e = 0; e < 8; ++e) o[e] = tap < T ? lds[row * RS + (c0 + e) * T + tap] : (__bf16)0.f;
         *(bf16x8*)(out + ((((int64_t)q * KSTEPS + ks) * NTT + nt) * 64 + lane) * 8) = o;
     }
 }
 __device__ __forceinline__ void pack_unit(const float* __restrict__ w, __bf16* __restrict__ out, int unit, int Ci, int Co, int CK, int T,
-                                          int mode, int A, int B, float* lds) {
+                                          int mode, int A, int B, __bf16* lds) {
     switch (mode) {
         case PK_CONV_FWD:
             if (CK == 32) pack_unit_t<32, 27, PK_CONV_FWD>(w, out, unit, Co, A, B, lds); else pack_unit_t<16, 27, PK_CONV_FWD>(w, out, unit, Co, A, B, lds);
@@ -132,13 +116,13 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, __bf16* _
 }
 __global__ void __launch_bounds__(256) k_mfma_pack(const float* __restrict__ w, __bf16* __restrict__ out, int Ci, int Co, int CK, int T,
                                                    int mode, int A, int B) {
-    __shared__ float lds[PACK_LDS_FLOATS];
+    __shared__ __bf16 lds[PACK_LDS_ELEMS];
     pack_unit(w, out, blockIdx.x, Ci, Co, CK, T, mode, A, B, lds);
 }
 // every filter pack of a plan in ONE launch: block -> (job, unit) by binary search over the jobs' first block index
 __global__ void __launch_bounds__(256) k_mfma_pack_batched(const float* __restrict__ params_base, char* __restrict__ ws,
                                                            const PackJob* __restrict__ jobs, int njobs) {
-    __shared__ float lds[PACK_LDS_FLOATS];
+    __shared__ __bf16 lds[PACK_LDS_ELEMS];
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
@@ -805,7 +789,6 @@ __global__ void __launch_bounds__(256, 2) k_conv_first_mfma(ConvFirstArgs a) {
 // overlap the MFMAs of plane p-1.  Same packed filter, arguments, epilogue semantics and statistics rows (one per
 // blockIdx.x) as k_mfma_conv_p<1,3,1,..,32,1,false>.
 // ------------------------------------------------------------------------------------------------
-struct ZWork { int nseg, zlen, cols_x, cols_y; };
 __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw) {
     constexpr int BY = 8, BX = 16, HY = BY + 2, HX = BX + 2, HXP = 20, PLANE_B = HY * HXP * 64, RING = 4;
     constexpr int UNITS = HY * HX * 4, ITERS = (UNITS + 255) / 256;
@@ -1151,6 +1134,7 @@ template <int BZ, int BY, int BX> static int launch_small(const MfmaConvArgs& a0
 }
 static int launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
     if (CK == 32) { const int gz = launch_conv_z(a, s); if (gz) return gz; }
+    else { const int gz = launch_conv_z16(a, s); if (gz) return gz; }
     Tile t = tile_s1k3(a.g, CK);
     if (CK == 32 && small_s1k3(a.g, CK)) return t.bx == 8 ? launch_small<2, 4, 8>(a, s) : launch_small<4, 4, 4>(a, s);
     if (t.bx == 16 && t.bz == 4) { if (CK == 32) return launch_nt<1, 3, 1, 4, 4, 16, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 8, 16, 16, false>(a, s); }

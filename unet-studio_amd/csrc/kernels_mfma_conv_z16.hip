@@ -1,0 +1,253 @@
+// Sliding-window 3x3x3 stride-1 convolution for a SINGLE 16-channel chunk (Cin = 16): the 16->16 layers at full resolution, forward
+// and dgrad, and the 16->32 dgrad of decode0.0.  k_mfma_conv_p serves these with 6x10x18 halo tiles (2.1x the outputs staged
+// through LDS) and one 1-KB LDS read per MFMA: at Cout = 16 a patch fragment feeds a single MFMA, and the kernel is LDS-read bound
+// (49 us for 134 MB at 128^3).
+//
+// Input-stationary along z: a block owns an 8x16 (y, x) footprint and walks z.  When input plane q is resident, its fragments are
+// read ONCE -- five k-steps (the nine (ky, kx) taps in pairs: K = 32 = two taps x 16 channels) per m-tile -- and every fragment
+// feeds three MFMAs, one per kz, into the accumulators of the three output planes q+1, q, q-1 that plane q contributes to.  The
+// accumulators rotate through registers (3 planes x 2 m-tiles x NT x 4 VGPRs); plane q-1 is complete after step q and leaves
+// through the epilogue.  LDS reads per MFMA: 1/3 KB instead of 1 KB; LDS holds three 5.6-KB planes instead of a 34-KB tile.
+//
+// The filter is the ordinary CK = 16 pack ([kstep][row tile][lane][8], taps paired in sequence 2ks, 2ks+1): the pairs this kernel
+// needs -- inside one kz -- are gathered lane by lane when the fragments are loaded, once per block.
+// Same arguments, epilogue semantics (bias, bf16, two destinations, accumulate, statistics rows per blockIdx.x) as k_mfma_conv_p.
+#include <cstdlib>
+#include <type_traits>
+
+#include "mfma_util.h"
+
+namespace unet {
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork zw) {
+    constexpr int BY = 8, BX = 16, HY = BY + 2, HX = BX + 2, PLANE_B = HY * HX * 32;
+    constexpr int UNITS = HY * HX * 2, ITERS = (UNITS + 255) / 256;
+    static_assert(ITERS == 2, "two 16-B units per thread and plane");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4, h = gq >> 1, lg = tid & 1;
+    const int nt0 = blockIdx.y * NT, NTT = g.Cout / 16, C0 = a.src[0].C;
+    const bf16x8* wp = (const bf16x8*)a.w;
+    const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+
+    // filter fragments wf[kz][s][n]: lanes of k-groups 0,1 hold tap 9 kz + 2s, k-groups 2,3 tap 9 kz + 2s + 1 (none for s = 4: zeros)
+    bf16x8 wf[3][5][NT];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int t = 2 * s + h, tg = kz * 9 + (t <= 8 ? t : 8);
+                const bf16x8 v = wp[((size_t)(tg >> 1) * NTT + nt0 + n) * 64 + ((lane & 31) | ((tg & 1) << 5))];
+                wf[kz][s][n] = t <= 8 ? v : zero8;
+            }
+    // patch address of k-step s in a plane for this lane's first m-tile (row 2 wave); the second m-tile is one row further
+    int mb[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int t = 2 * s + h <= 8 ? 2 * s + h : 8, ky = t / 3, kx = t % 3;    // (s = 4, upper k-groups: any resident data, times zero)
+        mb[s] = ((2 * wave + ky) * HX + j + kx) * 32 + (gq & 1) * 16;
+    }
+    // staging units of a plane
+    int ulds[ITERS], uyx[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int u = tid + it * 256, hv = u >> 1, hy = hv / HX, hx = hv % HX;
+        ulds[it] = u < UNITS ? (hy * HX + hx) * 32 + lg * 16 : -1;
+        uyx[it] = hy | (hx << 8);
+    }
+    const int c = lg * 8, sidx = (a.nsrc > 1 && c >= C0) ? 1 : 0;
+    const char* sptr = (const char*)(sidx ? a.src[1].ptr : a.src[0].ptr) + (size_t)(c - (sidx ? C0 : 0)) * 2;
+    const unsigned vstride = (unsigned)(sidx ? a.src[1].C : C0) * 2;
+
+    float s1[NT][4], s2[NT][4], b4[NT][4];
+    __amdgpu_buffer_rsrc_t orsrc[NT];
+    int oC[NT], cd[NT], oacc[NT];
+    bool ohave[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int cch = (nt0 + n) * 16 + gq * 4;                  // this lane's 4 output channels of row tile n
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1[n][r] = 0.f; s2[n][r] = 0.f; b4[n][r] = a.bias ? a.bias[cch + r] : 0.f; }
+        const int dsel = (a.nout > 1 && (nt0 + n) * 16 >= a.outC[0]) ? 1 : 0;      // uniform: destinations split at a multiple of 16
+        char* ob = (char*)(dsel ? a.out[1] : a.out[0]);
+        oC[n] = dsel ? a.outC[1] : a.outC[0];
+        oacc[n] = dsel ? a.out_acc[1] : a.out_acc[0];
+        cd[n] = cch - (dsel ? a.outC[0] : 0);
+        ohave[n] = ob != nullptr;
+        // outputs leave through a buffer descriptor: a lane outside the volume (or a plane outside the segment) stores beyond
+        // num_records and the hardware drops it -- no branch in the step
+        orsrc[n] = __builtin_amdgcn_make_buffer_rsrc(ob, 0, ob ? (int)((size_t)a.oD * a.oH * a.oW * oC[n] * 2) : 0, 0x00020000);
+    }
+    constexpr int OOB = (int)0x80000000;
+
+    const int nitems = zw.cols_x * zw.cols_y * zw.nseg;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int seg = item % zw.nseg, col = item / zw.nseg;
+        const int x0 = (col % zw.cols_x) * BX, y0 = (col / zw.cols_x) * BY;
+        const int zs = seg * zw.zlen, ze = zs + zw.zlen < g.D ? zs + zw.zlen : g.D;      // output planes [zs, ze)
+        bool uok[ITERS];
+        const char* ubase[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int gy = y0 - 1 + (uyx[it] & 255), gx = x0 - 1 + (uyx[it] >> 8);
+            uok[it] = ulds[it] >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            ubase[it] = sptr + (size_t)(uok[it] ? gy * g.W + gx : 0) * vstride;
+        }
+        const size_t plane_bytes = (size_t)g.H * g.W * vstride;
+        // plane index r is relative to zs - 1 (r = 0 is input plane zs - 1); loads are unconditional (clamped) and zeroed on the way
+        // into LDS when the unit or the plane lies outside the volume
+        auto load_plane = [&](int r, bf16x8 (&R)[ITERS]) {
+            int pz = zs - 1 + r;
+            pz = pz < 0 ? 0 : (pz > g.D - 1 ? g.D - 1 : pz);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) R[it] = *(const bf16x8*)(ubase[it] + (size_t)pz * plane_bytes);
+            __builtin_amdgcn_sched_barrier(0);       // issued here, a whole step ahead of their use (the scheduler sinks them to the end of the MFMAs)
+        };
+        auto store_plane = [&](int r, int buf, const bf16x8 (&R)[ITERS]) {
+            const int pz = zs - 1 + r;
+            const bool zin = (unsigned)pz < (unsigned)g.D;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                if (ulds[it] >= 0) *(bf16x8*)(smem + buf * PLANE_B + ulds[it]) = (zin && uok[it]) ? R[it] : zero8;
+        };
+        // output offsets of this lane's two voxels (rows 2 wave, 2 wave + 1) in plane zs; plane o = zs + k adds k planes
+        const int ox = x0 + j;
+        bool ook[2];
+        unsigned ooff[2][NT], oplane[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = y0 + 2 * wave + i;
+            ook[i] = oy < a.oH && ox < a.oW;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                ooff[i][n] = (unsigned)(((((size_t)zs * a.oH + (ook[i] ? oy : 0)) * a.oW + (ook[i] ? ox : 0)) * oC[n] + cd[n]) * 2);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) oplane[n] = (unsigned)((size_t)a.oH * a.oW * oC[n] * 2);
+
+        f32x4 acc[3][2][NT];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[q][i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // step r (phase PH = r mod 3): the fragments of plane r - 1 (buffer (PH + 2) % 3) feed output planes r (kz = 0, a fresh
+        // accumulator), r - 1 and r - 2 (relative to zs - 1: output plane zs + k is k + 1); the latter is complete and leaves
+        auto compute = [&](int r, auto phc) {
+            constexpr int PH = decltype(phc)::value, BQ = (PH + 2) % 3;
+            bf16x8 xr[2][5];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int s = 0; s < 5; ++s) xr[i][s] = *(const bf16x8*)(smem + BQ * PLANE_B + mb[s] + i * HX * 32);
+#pragma unroll
+            for (int s = 0; s < 5; ++s)
+#pragma unroll
+                for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            f32x4& d = acc[(PH - kz + 3) % 3][i][n];
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kz][s][n], xr[i][s], (kz == 0 && s == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d, 0, 0, 0);
+                        }
+            // epilogue of output plane k = r - 3 (zs + k), accumulator (PH + 1) % 3
+            const int k = r - 3;
+            const bool kin = k >= 0 && zs + k < ze;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 d = acc[(PH + 1) % 3][i][n];
+                    const bool ok = kin && ook[i] && ohave[n];
+                    const int off = ok ? (int)(ooff[i][n] + (unsigned)k * oplane[n]) : OOB;
+                    float v0 = d[0] + b4[n][0], v1 = d[1] + b4[n][1], v2 = d[2] + b4[n][2], v3 = d[3] + b4[n][3];
+                    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                    if (oacc[n]) {     // uniform; an out-of-range offset reads zeros
+                        const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(orsrc[n], off, 0, 0);
+                        v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+                    }
+                    u32x2 o;
+                    o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, orsrc[n], off, 0, 0);
+                    const float r0 = ok ? bf_lo(o.x) : 0.f, r1 = ok ? bf_hi(o.x) : 0.f, r2 = ok ? bf_lo(o.y) : 0.f, r3 = ok ? bf_hi(o.y) : 0.f;
+                    s1[n][0] += r0; s1[n][1] += r1; s1[n][2] += r2; s1[n][3] += r3;
+                    s2[n][0] = fmaf(r0, r0, s2[n][0]); s2[n][1] = fmaf(r1, r1, s2[n][1]);
+                    s2[n][2] = fmaf(r2, r2, s2[n][2]); s2[n][3] = fmaf(r3, r3, s2[n][3]);
+                }
+        };
+        // step r: request plane r + 1, compute on plane r - 1, then put plane r (requested one step ago) into buffer r % 3.  One barrier
+        // per step: buffer r % 3 was last read by the compute of step r - 2, which every wave finished before the barrier of step r - 1.
+        const int rlast = (ze - zs) + 2;          // last computing step (plane ze); rlast + 1 planes 0 .. ze - zs + 1 are needed
+        bf16x8 Ra[ITERS], Rb[ITERS];
+        __syncthreads();                           // previous item's planes are no longer read
+        load_plane(0, Ra);
+        load_plane(1, Rb);
+        store_plane(0, 0, Ra);
+        __syncthreads();
+        // unrolled by 6 = lcm(3 accumulator phases, 2 register sets); steps past rlast compute on stale planes and store nothing
+        for (int r = 1; r <= rlast; r += 6) {
+            load_plane(r + 1, Ra); compute(r, std::integral_constant<int, 1>{});     store_plane(r, 1, Rb);     __syncthreads();
+            load_plane(r + 2, Rb); compute(r + 1, std::integral_constant<int, 2>{}); store_plane(r + 1, 2, Ra); __syncthreads();
+            load_plane(r + 3, Ra); compute(r + 2, std::integral_constant<int, 0>{}); store_plane(r + 2, 0, Rb); __syncthreads();
+            load_plane(r + 4, Rb); compute(r + 3, std::integral_constant<int, 1>{}); store_plane(r + 3, 1, Ra); __syncthreads();
+            load_plane(r + 5, Ra); compute(r + 4, std::integral_constant<int, 2>{}); store_plane(r + 4, 2, Rb); __syncthreads();
+            load_plane(r + 6, Rb); compute(r + 5, std::integral_constant<int, 0>{}); store_plane(r + 5, 0, Ra); __syncthreads();
+        }
+    }
+    if (a.stats) {
+        float* red = (float*)smem;
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = s1[n][r], v = s2[n][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+                if (j == 0) { red[((wave * NT + n) * 16 + gq * 4 + r) * 2] = u; red[((wave * NT + n) * 16 + gq * 4 + r) * 2 + 1] = v; }
+            }
+        __syncthreads();
+        if (tid < NT * 16) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { u += red[((w * NT) * 16 + tid) * 2]; v += red[((w * NT) * 16 + tid) * 2 + 1]; }
+            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 0] = u;
+            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 1] = v;
+        }
+    }
+}
+
+int launch_conv_z16(const MfmaConvArgs& a0, hipStream_t s) {
+    const ConvGeom& g = a0.g;
+    static const bool off = getenv("UNET_NO_CONV_Z16") != nullptr;
+    if (off || g.Cin != 16 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
+    if (g.Cout != 16 && g.Cout != 32) return 0;
+    for (int k = 0; k < 2; ++k)   // outputs are addressed with 31-bit byte offsets through a buffer descriptor
+        if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return 0;
+    if (a0.nout > 1 && a0.outC[0] % 16) return 0;
+    ZWork zw;
+    zw.cols_x = (g.Wo + 15) / 16; zw.cols_y = (g.Ho + 7) / 8;
+    const int cols = zw.cols_x * zw.cols_y;
+    static const int want_env = getenv("UNET_Z16_BLOCKS") ? atoi(getenv("UNET_Z16_BLOCKS")) : 0;
+    const int gy = g.Cout / 16;                        // one row tile per block (two row tiles: 256 VGPRs and spills)
+    const int want = (want_env > 0 ? want_env : 512) / gy;    // two blocks per CU in total
+    int nseg = (want + cols - 1) / cols;
+    if (nseg < 1) nseg = 1;
+    int zlen = (g.Do + nseg - 1) / nseg;
+    if (zlen < 4) zlen = 4;
+    nseg = (g.Do + zlen - 1) / zlen;
+    zw.nseg = nseg; zw.zlen = zlen;
+    const int items = cols * nseg;
+    const int gx = items < want ? items : want;
+    constexpr int lds = 3 * 10 * 18 * 32;
+    k_mfma_conv_z16<1><<<dim3((unsigned)gx, (unsigned)gy), 256, lds, s>>>(a0, zw);
+    return gx;
+}
+
+}  // namespace unet

@@ -48,4 +48,27 @@ __device__ __forceinline__ uint4 transform8(uint4 v, bool xf, const float* sc, c
     return make_uint4(wv[0], wv[1], wv[2], wv[3]);
 }
 
+// arguments of the MFMA conv kernels (kernels_mfma_conv.hip, kernels_mfma_conv_z16.hip)
+struct MfmaConvArgs {
+    ConvGeom g;          // GEMM view: Cin = contraction channels, Cout = rows; D,H,W = volume read; Do,Ho,Wo = grid the tiles cover
+    SrcDesc src[2];
+    int nsrc;
+    const void* w;       // packed filter
+    const float* bias;   // nullptr: none (indexed by destination channel)
+    void* out[2];        // channels-last bf16 destinations (split at outC[0] channels)
+    int outC[2];
+    int out_acc[2];
+    int nout;
+    float* stats;        // [nblk][Cout][2] or nullptr
+    int tiles_x, tiles_y, tiles_z;
+    int sc_C;            // SC: destination channels per tap (rows = 8 * sc_C)
+    int oD, oH, oW;      // destination volume
+};
+
+// work split of the sliding-window kernels: (y, x) columns of the footprint x z segments of zlen output planes
+struct ZWork { int nseg, zlen, cols_x, cols_y; };
+// sliding window for a single 16-channel chunk (kernels_mfma_conv_z16.hip); returns 0 if the geometry does not qualify, else the
+// number of statistics rows (gridDim.x)
+int launch_conv_z16(const MfmaConvArgs& a, hipStream_t s);
+
 }  // namespace unet
