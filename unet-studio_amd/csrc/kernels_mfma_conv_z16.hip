@@ -6,8 +6,12 @@
 // Input-stationary along z: a block owns an 8x16 (y, x) footprint and walks z.  When input plane q is resident, its fragments are
 // read ONCE -- five k-steps (the nine (ky, kx) taps in pairs: K = 32 = two taps x 16 channels) per m-tile -- and every fragment
 // feeds three MFMAs, one per kz, into the accumulators of the three output planes q+1, q, q-1 that plane q contributes to.  The
-// accumulators rotate through registers (3 planes x 2 m-tiles x NT x 4 VGPRs); plane q-1 is complete after step q and leaves
-// through the epilogue.  LDS reads per MFMA: 1/3 KB instead of 1 KB; LDS holds three 5.6-KB planes instead of a 34-KB tile.
+// accumulators rotate through registers (3 planes x 2 m-tiles x 4 VGPRs); plane q-1 is complete after step q and leaves through
+// the epilogue.  LDS reads per MFMA: 1/3 KB instead of 1 KB.
+//
+// Planes travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, five planes ahead, a ring of six 5.6-KB planes): no staging registers
+// and no ds_write pass; the DMA is inline assembly waited for with a hand-counted vmcnt (see `dma` / `step`).  Blocks of an XCD own
+// a compact patch of columns of one z segment, so the halos they share are L2 hits.
 //
 // The filter is the ordinary CK = 16 pack ([kstep][row tile][lane][8], taps paired in sequence 2ks, 2ks+1): the pairs this kernel
 // needs -- inside one kz -- are gathered lane by lane when the fragments are loaded, once per block.
@@ -19,17 +23,23 @@
 
 namespace unet {
 
+// what LDS-DMA lanes outside the volume read (16 B of zeros, L2-resident)
+__device__ __attribute__((aligned(16))) unsigned g_z16_zero[4] = {0u, 0u, 0u, 0u};
+
 template <int NT>
 __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork zw) {
     constexpr int BY = 8, BX = 16, HY = BY + 2, HX = BX + 2, PLANE_B = HY * HX * 32;
-    constexpr int UNITS = HY * HX * 2, ITERS = (UNITS + 255) / 256;
-    static_assert(ITERS == 2, "two 16-B units per thread and plane");
+    // a plane = 360 16-B units, LDS image linear in unit order; wave w moves units [90 w, 90 w + 90): one 64-lane LDS-DMA and one of 26 lanes
+    constexpr int UNITS = HY * HX * 2, UPW = UNITS / 4, ITERS = 2;
+    constexpr int NBUF = 6, PF = 5;                 // ring of planes in LDS, planes requested ahead (NBUF >= PF + 1)
+    static_assert(UPW == 90 && NBUF % 3 == 0 && NBUF >= PF + 1, "unit split / ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom& g = a.g;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4, h = gq >> 1, lg = tid & 1;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4, h = gq >> 1, lg = lane & 1;
     const int nt0 = blockIdx.y * NT, NTT = g.Cout / 16, C0 = a.src[0].C;
     const bf16x8* wp = (const bf16x8*)a.w;
     const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;       // LDS byte address of the ring
 
     // filter fragments wf[kz][s][n]: lanes of k-groups 0,1 hold tap 9 kz + 2s, k-groups 2,3 tap 9 kz + 2s + 1 (none for s = 4: zeros)
     bf16x8 wf[3][5][NT];
@@ -50,13 +60,16 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
         const int t = 2 * s + h <= 8 ? 2 * s + h : 8, ky = t / 3, kx = t % 3;    // (s = 4, upper k-groups: any resident data, times zero)
         mb[s] = ((2 * wave + ky) * HX + j + kx) * 32 + (gq & 1) * 16;
     }
-    // staging units of a plane
-    int ulds[ITERS], uyx[ITERS];
+    // staging units of a plane (this lane's two units) and the wave-uniform LDS offsets of the two DMA pieces
+    int uyx[ITERS];
+    bool uact[ITERS];
+    unsigned upiece[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int u = tid + it * 256, hv = u >> 1, hy = hv / HX, hx = hv % HX;
-        ulds[it] = u < UNITS ? (hy * HX + hx) * 32 + lg * 16 : -1;
+        const int u = wave * UPW + it * 64 + lane, hv = u >> 1, hy = hv / HX, hx = hv % HX;
+        uact[it] = it * 64 + lane < UPW;
         uyx[it] = hy | (hx << 8);
+        upiece[it] = (unsigned)__builtin_amdgcn_readfirstlane((wave * UPW + it * 64) * 16);
     }
     const int c = lg * 8, sidx = (a.nsrc > 1 && c >= C0) ? 1 : 0;
     const char* sptr = (const char*)(sidx ? a.src[1].ptr : a.src[0].ptr) + (size_t)(c - (sidx ? C0 : 0)) * 2;
@@ -84,8 +97,13 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
     constexpr int OOB = (int)0x80000000;
 
     const int nitems = zw.cols_x * zw.cols_y * zw.nseg;
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int seg = item % zw.nseg, col = item / zw.nseg;
+    // Blocks of one XCD (blockIdx.x % 8) take a contiguous range of items, and items are ordered segment-major: an XCD then owns a
+    // compact patch of columns of ONE z segment, marching z together, and the (y, x) halos its blocks share are L2 hits.  Dealt
+    // round-robin, every halo was fetched by a different XCD: PMC 101 MB read per 67 MB input at 128^3 (1.41 x 1.06 = the halo
+    // ratio); with the patches 72 MB.
+    const int ncols = zw.cols_x * zw.cols_y;
+    for (int item = xcd_remap(blockIdx.x, gridDim.x); item < nitems; item += gridDim.x) {
+        const int seg = item / ncols, col = item % ncols;
         const int x0 = (col % zw.cols_x) * BX, y0 = (col / zw.cols_x) * BY;
         const int zs = seg * zw.zlen, ze = zs + zw.zlen < g.D ? zs + zw.zlen : g.D;      // output planes [zs, ze)
         bool uok[ITERS];
@@ -93,25 +111,28 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int gy = y0 - 1 + (uyx[it] & 255), gx = x0 - 1 + (uyx[it] >> 8);
-            uok[it] = ulds[it] >= 0 && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            uok[it] = uact[it] && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
             ubase[it] = sptr + (size_t)(uok[it] ? gy * g.W + gx : 0) * vstride;
         }
         const size_t plane_bytes = (size_t)g.H * g.W * vstride;
-        // plane index r is relative to zs - 1 (r = 0 is input plane zs - 1); loads are unconditional (clamped) and zeroed on the way
-        // into LDS when the unit or the plane lies outside the volume
-        auto load_plane = [&](int r, bf16x8 (&R)[ITERS]) {
-            int pz = zs - 1 + r;
-            pz = pz < 0 ? 0 : (pz > g.D - 1 ? g.D - 1 : pz);
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) R[it] = *(const bf16x8*)(ubase[it] + (size_t)pz * plane_bytes);
-            __builtin_amdgcn_sched_barrier(0);       // issued here, a whole step ahead of their use (the scheduler sinks them to the end of the MFMAs)
-        };
-        auto store_plane = [&](int r, int buf, const bf16x8 (&R)[ITERS]) {
+        const int rlast = (ze - zs) + 2;          // last computing step; planes 0 .. rlast - 1 (zs - 1 .. ze) are needed
+        // Plane r (relative to zs - 1) travels HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass),
+        // PF planes ahead of its use.  Units outside the volume, planes outside it and planes past the segment read a zero page.
+        // The DMA is inline assembly, so hipcc neither counts it nor waits for it: every step issues exactly 2 DMA pieces and 2 output
+        // stores per wave (stores outside the segment go to an out-of-range buffer offset), and plane r is awaited with
+        // s_waitcnt vmcnt(4 PF - 2) = everything younger than its second piece.
+        auto dma = [&](int r, int slot) {
             const int pz = zs - 1 + r;
-            const bool zin = (unsigned)pz < (unsigned)g.D;
+            const bool zin = (unsigned)pz < (unsigned)g.D && r < rlast;
 #pragma unroll
-            for (int it = 0; it < ITERS; ++it)
-                if (ulds[it] >= 0) *(bf16x8*)(smem + buf * PLANE_B + ulds[it]) = (zin && uok[it]) ? R[it] : zero8;
+            for (int it = 0; it < ITERS; ++it) {
+                const char* src = (zin && uok[it]) ? ubase[it] + (size_t)pz * plane_bytes : (const char*)g_z16_zero;
+                const unsigned dst = lds0 + (unsigned)slot * PLANE_B + upiece[it];
+                unsigned keep;
+                if (it == 0 || uact[it])
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
         };
         // output offsets of this lane's two voxels (rows 2 wave, 2 wave + 1) in plane zs; plane o = zs + k adds k planes
         const int ox = x0 + j;
@@ -136,15 +157,18 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[q][i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // step r (phase PH = r mod 3): the fragments of plane r - 1 (buffer (PH + 2) % 3) feed output planes r (kz = 0, a fresh
+        // step r (phase PH = r mod 3): the fragments of plane r - 1 (ring slot BQ) feed output planes r (kz = 0, a fresh
         // accumulator), r - 1 and r - 2 (relative to zs - 1: output plane zs + k is k + 1); the latter is complete and leaves
-        auto compute = [&](int r, auto phc) {
-            constexpr int PH = decltype(phc)::value, BQ = (PH + 2) % 3;
+        auto compute = [&](int r, auto phc, auto slc) {
+            constexpr int PH = decltype(phc)::value, BQ = decltype(slc)::value;
             bf16x8 xr[2][5];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int s = 0; s < 5; ++s)
 #pragma unroll
-                for (int s = 0; s < 5; ++s) xr[i][s] = *(const bf16x8*)(smem + BQ * PLANE_B + mb[s] + i * HX * 32);
+                for (int i = 0; i < 2; ++i) xr[i][s] = *(const bf16x8*)(smem + BQ * PLANE_B + mb[s] + i * HX * 32);
+            // all ten reads are in flight before the first MFMA (left alone the scheduler issues them two at a time, each pair followed by
+            // a wait: five exposed LDS latencies per step at two waves per SIMD)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 5; ++s)
 #pragma unroll
@@ -181,28 +205,44 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
                     s2[n][2] = fmaf(r2, r2, s2[n][2]); s2[n][3] = fmaf(r3, r3, s2[n][3]);
                 }
         };
-        // step r: request plane r + 1, compute on plane r - 1, then put plane r (requested one step ago) into buffer r % 3.  One barrier
-        // per step: buffer r % 3 was last read by the compute of step r - 2, which every wave finished before the barrier of step r - 1.
-        const int rlast = (ze - zs) + 2;          // last computing step (plane ze); rlast + 1 planes 0 .. ze - zs + 1 are needed
-        bf16x8 Ra[ITERS], Rb[ITERS];
-        __syncthreads();                           // previous item's planes are no longer read
-        load_plane(0, Ra);
-        load_plane(1, Rb);
-        store_plane(0, 0, Ra);
-        __syncthreads();
-        // unrolled by 6 = lcm(3 accumulator phases, 2 register sets); steps past rlast compute on stale planes and store nothing
+        // step r: wait for plane r - 1, barrier (every wave's pieces have landed; every wave is done with plane r - 2, whose slot
+        // plane r - 1 + PF overwrites: NBUF >= PF + 1), request plane r - 1 + PF, compute on plane r - 1.
+        auto step = [&](int r, auto phc, auto slc) {
+            constexpr int SL = decltype(slc)::value;      // slot of plane r - 1
+            static_assert(PF == 5, "vmcnt below = 4 PF - 2");
+            asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+            dma(r - 1 + PF, (SL + PF) % NBUF);
+            compute(r, phc, slc);
+        };
+        // the previous item's planes are no longer read, and its last requests (never used) have landed: slots can be refilled
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            dma(r, r);
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) {      // two out-of-range stores: the prologue's operations count like a step's
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, orsrc[0], OOB + 8 * (r * 2 * NT + i), 0, 0);   // (distinct: identical stores are merged)
+            }
+        }
+        // unrolled by 6 = lcm(3 accumulator phases, NBUF ring slots); plane r - 1 sits in slot (r - 1) % 6
         for (int r = 1; r <= rlast; r += 6) {
-            load_plane(r + 1, Ra); compute(r, std::integral_constant<int, 1>{});     store_plane(r, 1, Rb);     __syncthreads();
-            load_plane(r + 2, Rb); compute(r + 1, std::integral_constant<int, 2>{}); store_plane(r + 1, 2, Ra); __syncthreads();
-            load_plane(r + 3, Ra); compute(r + 2, std::integral_constant<int, 0>{}); store_plane(r + 2, 0, Rb); __syncthreads();
-            load_plane(r + 4, Rb); compute(r + 3, std::integral_constant<int, 1>{}); store_plane(r + 3, 1, Ra); __syncthreads();
-            load_plane(r + 5, Ra); compute(r + 4, std::integral_constant<int, 2>{}); store_plane(r + 4, 2, Rb); __syncthreads();
-            load_plane(r + 6, Rb); compute(r + 5, std::integral_constant<int, 0>{}); store_plane(r + 5, 0, Ra); __syncthreads();
+            step(r, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            if (r + 1 > rlast) break;
+            step(r + 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+            if (r + 2 > rlast) break;
+            step(r + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            if (r + 3 > rlast) break;
+            step(r + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+            if (r + 4 > rlast) break;
+            step(r + 4, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            if (r + 5 > rlast) break;
+            step(r + 5, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // outstanding requests write LDS: let them land before it is reused
     if (a.stats) {
         float* red = (float*)smem;
-        __syncthreads();
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -245,7 +285,7 @@ int launch_conv_z16(const MfmaConvArgs& a0, hipStream_t s) {
     zw.nseg = nseg; zw.zlen = zlen;
     const int items = cols * nseg;
     const int gx = items < want ? items : want;
-    constexpr int lds = 3 * 10 * 18 * 32;
+    constexpr int lds = 6 * 10 * 18 * 32;
     k_mfma_conv_z16<1><<<dim3((unsigned)gx, (unsigned)gy), 256, lds, s>>>(a0, zw);
     return gx;
 }
