@@ -850,8 +850,11 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
     const int nitems = zw.cols_x * zw.cols_y * zw.nseg;
     bf16x8 R[ITERS], R2[ITERS];
     const bf16x8 zero8 = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u));
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int seg = item % zw.nseg, col = item / zw.nseg;
+    // blocks of one XCD take a contiguous range of items, ordered segment-major: a compact patch of columns of one z segment whose
+    // shared (y, x) halos are L2 hits (dealt round-robin every halo was fetched by another XCD; see k_mfma_conv_z16)
+    const int ncols = zw.cols_x * zw.cols_y;
+    for (int item = xcd_remap(blockIdx.x, gridDim.x); item < nitems; item += gridDim.x) {
+        const int seg = item / ncols, col = item % ncols;
         const int x0 = (col % zw.cols_x) * BX, y0 = (col / zw.cols_x) * BY;
         const int zs = seg * zw.zlen, ze = zs + zw.zlen < g.D ? zs + zw.zlen : g.D;      // output planes [zs, ze)
         // per-column constants: which staging units lie inside the volume (y, x) and their address in plane 0 of the column

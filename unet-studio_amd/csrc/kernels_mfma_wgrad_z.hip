@@ -69,10 +69,11 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
     const int caB = ((int)blockIdx.y / CBG) * PA, cbB = ((int)blockIdx.y % CBG) * PB;
     const int C0 = a.asrc[0].C;
 
-    // this block's item: footprint column and z segment (blocks that share an XCD get neighbouring items: shared halos in one L2)
+    // this block's item: footprint column and z segment.  Blocks that share an XCD get a contiguous range of items, ordered
+    // segment-major: a compact patch of columns of one z segment, whose shared (y, x) halos are hits in that XCD's L2
     const int item = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int nsegs = a.nseg < 0 ? -a.nseg : a.nseg;
-    const int seg = item % nsegs, col = item / nsegs;
+    const int ncols = a.cols_x * a.cols_y;
+    const int seg = item / ncols, col = item % ncols;
     const int x0 = (col % a.cols_x) * BX, y0 = (col / a.cols_x) * BY;
     const int zs = seg * a.zlen, ze = zs + a.zlen < g.D ? zs + a.zlen : g.D, len = ze - zs;
 
