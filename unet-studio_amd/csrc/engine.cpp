@@ -447,6 +447,13 @@ struct Exec {
                             nb = stats_blocks(T.voxels());
                             dbl = p.dtype == UNET_DTYPE_F32;
                         }
+                        // few partial rows (32^3 and deeper): finalize + activated copy in one launch
+                        if (!dbl && p.a_off[n.tensor] != SIZE_MAX &&
+                            launch_norm_finalize_apply(p.dtype, partial(), nb, n.C, T.voxels(), params[n.gamma], params[n.beta], n.eps,
+                                                       stat(op.norm), n.batch ? buffers[n.buffer] : nullptr,
+                                                       n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, tptr(n.tensor), T.act,
+                                                       ws + p.a_off[n.tensor], s))
+                            break;
                         launch_norm_finalize(partial(), nb, n.C, T.voxels(), params[n.gamma], params[n.beta],
                                              n.eps, stat(op.norm), n.batch ? buffers[n.buffer] : nullptr,
                                              n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, s, dbl);
@@ -491,6 +498,9 @@ struct Exec {
         if (T.norm >= 0) {
             const Norm& n = p.g.norms[T.norm];
             launch_norm_bwd_partial(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), T.act, partial(), s);
+            if (launch_norm_bwd_finalize_apply(p.dtype, partial(), stats_blocks(T.voxels()), T.C, T.voxels(), params[n.gamma], stat(T.norm),
+                                               coef(T.norm), gparams[n.gamma], gparams[n.beta], gptr(t), tptr(t), T.act, s))
+                return;
             launch_norm_bwd_finalize(partial(), stats_blocks(T.voxels()), T.C, T.voxels(), params[n.gamma], stat(T.norm), coef(T.norm),
                                      gparams[n.gamma], gparams[n.beta], s, p.dtype == UNET_DTYPE_F32);
             launch_norm_bwd_apply(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), coef(T.norm), T.act, s);

@@ -87,6 +87,14 @@ void launch_norm_bwd_partial(int dtype, void* g, const void* u, int C, int64_t S
 // pass 2: coef[0..C) = gamma*rstd, [C..2C) = mean(dv), [2C..3C) = mean(dv*xhat); dgamma += sum dv*xhat, dbeta += sum dv
 void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat, float* coef,
                               float* dgamma, float* dbeta, hipStream_t s, bool dbl = false);
+// finalize + activated copy in ONE launch where the partial rows are few (bf16, <= 128 rows, C <= 512): returns false when the
+// shape does not qualify (the caller then uses launch_norm_finalize + launch_apply_view)
+bool launch_norm_finalize_apply(int dtype, const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
+                                float* stat, float* running_mean, float* running_var, double momentum, const void* raw, int act, void* out,
+                                hipStream_t s);
+// the same for passes 2 + 3 of the backward
+bool launch_norm_bwd_finalize_apply(int dtype, const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat,
+                                    float* coef, float* dgamma, float* dbeta, void* g, const void* u, int act, hipStream_t s);
 // pass 3: g <- du = coef0 * (dv - m1 - xhat*m2)
 void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, const float* stat, const float* coef, int act,
                            hipStream_t s);

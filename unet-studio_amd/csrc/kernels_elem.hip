@@ -379,6 +379,52 @@ void launch_norm_bwd_finalize(const float* partial, int nblk, int C, int64_t S, 
     k_norm_bwd_finalize<<<C, nblk > 128 ? 256 : 64, 0, s>>>(partial, nblk, C, S, gamma, stat, coef, dgamma, dbeta, dbl ? 1 : 0);
 }
 
+// norm backward with few partial rows: k_norm_bwd_finalize in the prologue of k_norm_bwd_apply8 (see k_norm_finalize_apply8)
+__device__ __forceinline__ void prologue_sums(const float* __restrict__ partial, int nblk, int C, double* sa, double* sb);
+__global__ void __launch_bounds__(256) k_norm_bwd_finalize_apply8(const float* __restrict__ partial, int nblk, int C, int64_t S, int64_t VPB,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ stat,
+                                                                  float* __restrict__ coef, float* dgamma, float* dbeta,
+                                                                  uint4* __restrict__ g8, const uint4* __restrict__ u8, int act) {
+    __shared__ double sa[512], sb[512];
+    __shared__ float s_c0[512], s_m1[512], s_m2[512];
+    prologue_sums(partial, nblk, C, sa, sb);
+    for (int c = threadIdx.x; c < C; c += 256) {          // k_norm_bwd_finalize's arithmetic
+        s_c0[c] = gamma[c] * stat[C + c];
+        s_m1[c] = (float)(sa[c] / (double)S);
+        s_m2[c] = (float)(sb[c] / (double)S);
+        if (blockIdx.x == 0) {
+            coef[c] = s_c0[c]; coef[C + c] = s_m1[c]; coef[2 * C + c] = s_m2[c];
+            dgamma[c] += (float)sb[c];
+            dbeta[c] += (float)sa[c];
+        }
+    }
+    __syncthreads();
+    const int G8 = C / 8, NV = 256 / G8, grp = threadIdx.x % G8, lane = threadIdx.x / G8, c0 = grp * 8;
+    const int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
+    float sc[8], sh[8], A[8], B[8], D[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const float mean = stat[c], rstd = stat[C + c];
+        sc[e] = stat[2 * C + c]; sh[e] = stat[3 * C + c];
+        A[e] = s_c0[c];
+        B[e] = -s_c0[c] * rstd * s_m2[c];
+        D[e] = -s_c0[c] * (s_m1[c] - mean * rstd * s_m2[c]);
+    }
+    for (int64_t v = v0 + lane; v < v1; v += NV) {
+        float uf[8], gf[8];
+        unpack8(u8[v * G8 + grp], uf);
+        unpack8(g8[v * G8 + grp], gf);
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float r0 = fmaf(A[e] * gf[e], act_d(fmaf(uf[e], sc[e], sh[e]), act), fmaf(B[e], uf[e], D[e]));
+            float r1 = fmaf(A[e + 1] * gf[e + 1], act_d(fmaf(uf[e + 1], sc[e + 1], sh[e + 1]), act), fmaf(B[e + 1], uf[e + 1], D[e + 1]));
+            w[e / 2] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(r0)) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(r1)) << 16);
+        }
+        g8[v * G8 + grp] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
 template <typename T> __global__ void k_norm_bwd_apply(T* __restrict__ g, const T* __restrict__ u, int C, int64_t n,
                                                        const float* __restrict__ stat, const float* __restrict__ coef, int act) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -398,6 +444,17 @@ void launch_norm_bwd_apply(int dtype, void* g, const void* u, int C, int64_t S, 
         return;
     }
     UNET_DISPATCH(dtype, (k_norm_bwd_apply<T><<<cdiv64(S * C, 256), 256, 0, s>>>((T*)g, (const T*)u, C, S * C, stat, coef, act)));
+}
+
+static inline bool fused_norm_ok(int dtype, int C, int nblk);
+static inline int64_t fused_vpb(int C, int64_t S);
+bool launch_norm_bwd_finalize_apply(int dtype, const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* stat,
+                                    float* coef, float* dgamma, float* dbeta, void* g, const void* u, int act, hipStream_t s) {
+    if (!fused_norm_ok(dtype, C, nblk)) return false;
+    const int64_t vpb = fused_vpb(C, S);
+    k_norm_bwd_finalize_apply8<<<cdiv64(S, vpb), 256, 0, s>>>(partial, nblk, C, S, vpb, gamma, stat, coef, dgamma, dbeta, (uint4*)g,
+                                                              (const uint4*)u, act);
+    return true;
 }
 
 template <typename T> __global__ void k_act_bwd(T* __restrict__ g, const T* __restrict__ u, int act, int64_t n) {
@@ -567,6 +624,101 @@ void launch_apply_view(int dtype, SrcDesc src, void* out, int64_t S, hipStream_t
     } else {
         launch_materialize(dtype, &src, 1, out, S, s);
     }
+}
+
+// ---- few partial rows (the 32^3 and deeper levels): the finalize moves into the prologue of the consumer ----
+// A kernel boundary costs ~5 us whatever the kernel does, and at these levels k_norm_finalize / k_norm_bwd_finalize ARE that cost (22 + 22
+// launches of 4.7 us per step).  With <= 128 partial rows every block of the element-wise pass can re-sum them itself: C x rows x 8 B
+// from L2 (<= 64 KB), one thread per (channel, row quarter), fp64, fixed order; block 0 also leaves the values the later passes read
+// (stat / coef, running statistics, dgamma / dbeta).  (For the 64^3 and 128^3 levels -- 512..1024 rows -- that re-read is as much L2
+// traffic as the tensor itself, measured slower: they keep the separate finalize.)
+constexpr int FUSED_MAX_ROWS = 128, FUSED_MAX_C = 512;
+__device__ __forceinline__ void prologue_sums(const float* __restrict__ partial, int nblk, int C, double* sa, double* sb) {
+    // sa / sb: LDS, 512 doubles each.  A thread owns a channel PAIR (one 16-B load per row: {a, b} of two channels) and every RG-th row;
+    // its loads are issued sixteen at a time before the first add (one load per trip of a rolled loop is one exposed L2 latency per
+    // row: the first version of this prologue took longer than the launch it saved); the RG row groups of a channel are then added in order.
+    const int CP = C / 2, RG = CP >= 256 ? 1 : 256 / CP;
+    for (int idx = threadIdx.x; idx < CP * RG; idx += 256) {
+        const int cp = idx % CP, rg = idx / CP;
+        double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+        for (int r0 = rg; r0 < nblk; r0 += 16 * RG) {
+            float4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = r0 + k * RG;
+                v[k] = r < nblk ? *(const float4*)(partial + ((int64_t)r * C + 2 * cp) * 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { a0 += v[k].x; b0 += v[k].y; a1 += v[k].z; b1 += v[k].w; }
+        }
+        sa[rg * C + 2 * cp] = a0; sb[rg * C + 2 * cp] = b0; sa[rg * C + 2 * cp + 1] = a1; sb[rg * C + 2 * cp + 1] = b1;
+    }
+    __syncthreads();
+    if (RG > 1) {
+        for (int c = threadIdx.x; c < C; c += 256) {         // C <= 256 here: one pass; a thread reads its channel's RG sums, then overwrites slot 0
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < RG; ++q) { a += sa[q * C + c]; b += sb[q * C + c]; }
+            sa[c] = a; sb[c] = b;                            // slot (0, c) is only read by this thread
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_norm_finalize_apply8(const float* __restrict__ partial, int nblk, int C, int64_t S, int64_t VPB,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, double eps,
+                                                              float* __restrict__ stat, float* rm, float* rv, double momentum,
+                                                              const uint4* __restrict__ in, int act, uint4* __restrict__ out) {
+    __shared__ double sa[FUSED_MAX_C], sb[FUSED_MAX_C];
+    __shared__ float s_sc[FUSED_MAX_C], s_sh[FUSED_MAX_C];
+    prologue_sums(partial, nblk, C, sa, sb);
+    for (int c = threadIdx.x; c < C; c += 256) {          // k_norm_finalize's arithmetic
+        const double mean = sa[c] / (double)S;
+        double var = sb[c] / (double)S - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + eps), sc = (double)gamma[c] * rstd;
+        s_sc[c] = (float)sc; s_sh[c] = (float)((double)beta[c] - mean * sc);
+        if (blockIdx.x == 0) {
+            stat[c] = (float)mean; stat[C + c] = (float)rstd; stat[2 * C + c] = s_sc[c]; stat[3 * C + c] = s_sh[c];
+            if (rm) {
+                rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mean);
+                rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * (S > 1 ? var * (double)S / (double)(S - 1) : var));
+            }
+        }
+    }
+    __syncthreads();
+    const int G8 = C / 8, NV = 256 / G8, grp = threadIdx.x % G8, lane = threadIdx.x / G8, c0 = grp * 8;
+    const int64_t v0 = (int64_t)blockIdx.x * VPB, v1 = v0 + VPB < S ? v0 + VPB : S;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_sc[c0 + e]; sh[e] = s_sh[c0 + e]; }
+    for (int64_t v = v0 + lane; v < v1; v += NV) {
+        const uint4 r = in[v * G8 + grp];
+        unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float lo = act_f(fmaf(__uint_as_float(w[e] << 16), sc[2 * e], sh[2 * e]), act);
+            float hi = act_f(fmaf(__uint_as_float(w[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), act);
+            w[e] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(lo)) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(hi)) << 16);
+        }
+        out[v * G8 + grp] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+static inline bool fused_norm_ok(int dtype, int C, int nblk) {
+    static const bool off = getenv("UNET_NO_FUSED_FINALIZE") != nullptr;
+    return !off && dtype == 1 && C % 8 == 0 && C <= FUSED_MAX_C && 256 % (C / 8) == 0 && nblk <= FUSED_MAX_ROWS;
+}
+static inline int64_t fused_vpb(int C, int64_t S) {
+    const int64_t nv = 256 / (C / 8);
+    int64_t vpb = (S + 255) / 256;                     // <= 256 blocks: every block repeats the prologue
+    if (vpb < 2 * nv) vpb = 2 * nv;
+    return (vpb + nv - 1) / nv * nv;
+}
+bool launch_norm_finalize_apply(int dtype, const float* partial, int nblk, int C, int64_t S, const float* gamma, const float* beta, double eps,
+                                float* stat, float* rm, float* rv, double momentum, const void* raw, int act, void* out, hipStream_t s) {
+    if (!fused_norm_ok(dtype, C, nblk)) return false;
+    const int64_t vpb = fused_vpb(C, S);
+    k_norm_finalize_apply8<<<cdiv64(S, vpb), 256, 0, s>>>(partial, nblk, C, S, vpb, gamma, beta, eps, stat, rm, rv, momentum,
+                                                          (const uint4*)raw, act, (uint4*)out);
+    return true;
 }
 
 void launch_materialize(int dtype, const SrcDesc* src, int nsrc, void* out, int64_t S, hipStream_t s) {
