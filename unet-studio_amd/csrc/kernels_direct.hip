@@ -844,14 +844,26 @@ template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_bwd(
     float acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
-    for (int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc; v0 < a.S; v0 += vstride) {
-        float x[16], d[CO];
-        load_chunk16<T>(a.src, plain, v0, c0, true, x);
+    // the next voxel's operands are requested before this voxel's 200 FMAs (a thread walks ~16 voxels; one load -> use round trip
+    // per voxel left the level-0 head at 63 us for 184 MB)
+    auto fetch = [&](int64_t v, float (&xo)[16], float (&dout)[CO]) {
+        load_chunk16<T>(a.src, plain, v, c0, true, xo);
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
-            d[c] = 0.f;
-            if (c < a.Cout) d[c] = a.dy_planes ? a.dy_planes[(int64_t)c * a.S + v0] : ld<T>((const T*)a.dy_cl, v0 * a.Cout + c);
+            dout[c] = 0.f;
+            if (c < a.Cout) dout[c] = a.dy_planes ? a.dy_planes[(int64_t)c * a.S + v] : ld<T>((const T*)a.dy_cl, v * a.Cout + c);
         }
+    };
+    float xn[16], dn[CO];
+    int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc;
+    if (v0 < a.S) fetch(v0, xn, dn);
+    for (; v0 < a.S; v0 += vstride) {
+        float x[16], d[CO];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = xn[k];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) d[c] = dn[c];
+        if (v0 + vstride < a.S) fetch(v0 + vstride, xn, dn);
         if (a.slab) {
 #pragma unroll
             for (int c = 0; c < CO; ++c) {

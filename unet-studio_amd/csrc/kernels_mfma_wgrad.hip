@@ -510,31 +510,64 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_first_mfma(FirstWgradArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // A tile's global data (halo elements and dy units of this thread) rides in registers while the previous tile is computed: the
+    // loop used to be load -> LDS -> barrier -> compute per tile, 8 tiles per block, every load latency exposed (45 us at 128^3 for
+    // 71 MB) -- and this kernel is the LAST of the backward, on the critical path of the step.
+    constexpr int XI = (HZ * HY * (TX + 2) + 255) / 256, DI = NROW * TX * (CO / 8) / 256;
+    static_assert(NROW * TX * (CO / 8) % 256 == 0, "dy units per thread");
+    unsigned short xr[XI];
+    uint4 dr[DI];
+    auto gload = [&](int t) {
         const int x0 = (t % a.tiles_x) * TX, y0 = ((t / a.tiles_x) % a.tiles_y) * TY, z0 = (t / (a.tiles_x * a.tiles_y)) * TZ;
-        __syncthreads();
-        // input halo, three shifted copies: copy s holds x[.., x0 - 1 + i + s] at element i
-        for (int e = tid; e < HZ * HY * (TX + 2); e += 256) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int e = tid + i * 256;
             const int hx = e % (TX + 2), r = e / (TX + 2), hy = r % HY, hz = r / HY;
             const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             unsigned short v = 0;
-            if ((unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W) v = x[((size_t)gz * g.H + gy) * g.W + gx];
-#pragma unroll
-            for (int sft = 0; sft < 3; ++sft) {
-                const int i = hx - sft;
-                if (i >= 0 && i < TX) *(unsigned short*)(sm + (sft * XCOPY + (hz * HY + hy) * TX + i) * 2) = v;
-            }
+            if (e < HZ * HY * (TX + 2) && (unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
+                v = x[((size_t)gz * g.H + gy) * g.W + gx];
+            xr[i] = v;
         }
-        // dy tile [row][voxel][co] (16-B global reads, 4-B LDS stores)
-        for (int u = tid; u < NROW * TX * (CO / 8); u += 256) {
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+            const int u = tid + i * 256;
             const int c8 = u % (CO / 8), vx = (u / (CO / 8)) % TX, row = u / ((CO / 8) * TX);
             const int gz = z0 + row / TY, gy = y0 + row % TY, gx = x0 + vx;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (gz < g.D && gy < g.H && gx < g.W) v = *(const uint4*)(dyb + ((((size_t)gz * g.H + gy) * g.W + gx) * CO + c8 * 8) * 2);
-            unsigned* d = (unsigned*)(sm + DY_OFF + (row * TX + vx) * VSB + c8 * 16);
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            dr[i] = v;
         }
+    };
+    auto lstore = [&]() {
+        // input halo, three shifted copies: copy s holds x[.., x0 - 1 + i + s] at element i
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int e = tid + i * 256;
+            if (e < HZ * HY * (TX + 2)) {
+                const int hx = e % (TX + 2), r = e / (TX + 2), hy = r % HY, hz = r / HY;
+#pragma unroll
+                for (int sft = 0; sft < 3; ++sft) {
+                    const int k = hx - sft;
+                    if (k >= 0 && k < TX) *(unsigned short*)(sm + (sft * XCOPY + (hz * HY + hy) * TX + k) * 2) = xr[i];
+                }
+            }
+        }
+        // dy tile [row][voxel][co] (4-B LDS stores)
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+            const int u = tid + i * 256;
+            const int c8 = u % (CO / 8), vx = (u / (CO / 8)) % TX, row = u / ((CO / 8) * TX);
+            unsigned* d = (unsigned*)(sm + DY_OFF + (row * TX + vx) * VSB + c8 * 16);
+            d[0] = dr[i].x; d[1] = dr[i].y; d[2] = dr[i].z; d[3] = dr[i].w;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) gload(blockIdx.x);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();               // the previous tile's LDS image is no longer read
+        lstore();
         __syncthreads();
+        if (t + (int)gridDim.x < ntiles) gload(t + gridDim.x);
 #pragma unroll 1
         for (int row = wave; row < NROW; row += 4) {      // one K-step = the 32 voxels of output row `row`
             const int rz = row / TY, ry = row % TY;
