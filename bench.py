@@ -167,6 +167,16 @@ def op_flops(o):
     return 0.0
 
 
+def op_bytes(o, cat, esize):
+    """algorithmic HBM bytes of one conv / conv_trans launch: every operand once (activations at `esize` bytes per element, the packed
+    filter at esize, the weight gradient in fp32); re-reads (halos, accumulating epilogues, slabs) are NOT algorithmic"""
+    vi = o["in_dims"][0] * o["in_dims"][1] * o["in_dims"][2]
+    vo = o["out_dims"][0] * o["out_dims"][1] * o["out_dims"][2]
+    taps = o["ks"] ** 3 if o["kind"] == 1 else 8
+    act = (vi * o["cin"] + vo * o["cout"]) * esize
+    return act + taps * o["cin"] * o["cout"] * (4 if cat == "wgrad" else esize)
+
+
 def profile_steps(U, trainer, plan, peak, nsteps=3):
     """Per-op HIP-event brackets (include/unet_hip.h: unet_profile_begin/end) over `nsteps` optimizer steps: kernel time by family,
     conv MFMA fraction, and the single launch with the largest share of the conv time."""
@@ -194,7 +204,7 @@ def profile_steps(U, trainer, plan, peak, nsteps=3):
     if best is not None:
         o = ops[best[0]]
         fl = op_flops(o)
-        out["dominant"] = {"op": o["name"], "pass": best[1], "flops": fl, "ms": best[2],
+        out["dominant"] = {"op": o["name"], "pass": best[1], "flops": fl, "ms": best[2], "bytes": op_bytes(o, best[1], 2 if peak == PEAK_BF16 else 4),
                            "share_of_conv_time": best[2] / conv_ms if conv_ms > 0 else None,
                            "shape": "%d->%d k%d s%d @%s" % (o["cin"], o["cout"], o["ks"], o["stride"], "x".join(str(d) for d in o["out_dims"]))}
     return out
@@ -344,26 +354,40 @@ def main():
             out["kernel_ms_by_family"] = prof["kernel_ms_by_family"]
             d = prof.get("dominant")
             if d:
-                out["roofline"] = {"bound": "mfma", "achieved": d["flops"] / (d["ms"] * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                                   "frac": d["flops"] / (d["ms"] * 1e-3) / peak, "traffic": None,
-                                   "kernel": "%s of %s (%s): the launch with the largest share of the step's conv kernel time (%.1f %%), "
-                                             "HIP events around it inside %d profiled steps"
-                                             % (d["pass"], d["op"], d["shape"], 100.0 * d["share_of_conv_time"], prof["profiled_steps"]),
-                                   "avg_launch_ms": d["ms"]}
+                # the roofline that binds this launch: the longer of (algorithmic FLOPs / dense MFMA peak) and (algorithmic bytes / HBM peak)
+                t_mfma, t_hbm, sec = d["flops"] / peak, d["bytes"] / PEAK_HBM, d["ms"] * 1e-3
+                tr_name = {("wgrad", "32->16 k3 s1 @128x128x128"): "wgrad_kernel_traffic",
+                           ("conv_fwd", "32->16 k3 s1 @128x128x128"): "dominant_kernel_traffic"}.get((d["pass"], d["shape"])) if a.dtype == "bf16" else None
+                tr_b, tr_src = recorded_traffic(tr_name) if tr_name else (None, None)
+                rl = {"bound": "hbm", "achieved": d["bytes"] / sec / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": t_hbm / sec} if t_hbm >= t_mfma else \
+                     {"bound": "mfma", "achieved": d["flops"] / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": t_mfma / sec}
+                rl.update({"traffic": tr_b, "traffic_source": tr_src,
+                           "kernel": "%s of %s (%s): the launch with the largest share of the step's conv kernel time (%.1f %%), "
+                                     "HIP events around it inside %d profiled steps"
+                                     % (d["pass"], d["op"], d["shape"], 100.0 * d["share_of_conv_time"], prof["profiled_steps"]),
+                           "avg_launch_ms": d["ms"], "algorithmic_bytes": d["bytes"], "algorithmic_flops": d["flops"],
+                           "mfma_frac": t_mfma / sec, "hbm_frac": t_hbm / sec})
+                out["roofline"] = rl
         if n == 128 and cin == 1 and not a.no_kernels:
+            esz = 2 if a.dtype == "bf16" else 4
+
+            def entry(name, fl, by, sec, tr_name):
+                t_mfma, t_hbm = fl / peak, by / PEAK_HBM
+                tr_b, tr_src = recorded_traffic(tr_name) if a.dtype == "bf16" else (None, None)
+                e = {"kernel": name, "avg_launch_ms": sec * 1e3, "algorithmic_flops": fl, "algorithmic_bytes": by,
+                     "mfma_frac": t_mfma / sec, "hbm_frac": t_hbm / sec, "traffic": tr_b, "traffic_source": tr_src}
+                e.update({"bound": "hbm", "achieved": by / sec / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": t_hbm / sec} if t_hbm >= t_mfma else
+                         {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": t_mfma / sec})
+                return e
             kflops, ksec = dominant_kernel(U, n, a.dtype)
-            tr_b, tr_src = recorded_traffic("dominant_kernel_traffic") if a.dtype == "bf16" else (None, None)
-            kernels.append({"kernel": "conv3d fwd 32->16 3x3x3 @%d^3 (decode0.0, 23.7%% of forward FLOPs), unet_op_conv3d_fwd_packed" % n,
-                            "bound": "mfma", "achieved": kflops / ksec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": kflops / ksec / peak,
-                            "avg_launch_ms": ksec * 1e3, "traffic": tr_b, "traffic_source": tr_src})
+            kernels.append(entry("conv3d fwd 32->16 3x3x3 @%d^3 (decode0.0, 23.7%% of forward FLOPs), unet_op_conv3d_fwd_packed" % n, kflops,
+                                 n ** 3 * (32 + 16) * esz + 27 * 32 * 16 * esz, ksec, "dominant_kernel_traffic"))
             wflops, wsec = dominant_wgrad(U, n, a.dtype)
-            tr_b, tr_src = recorded_traffic("wgrad_kernel_traffic") if a.dtype == "bf16" else (None, None)
-            kernels.append({"kernel": "conv3d wgrad 32->16 3x3x3 @%d^3 (decode0.0) + slab reduce, unet_op_conv3d_bwd_weight" % n,
-                            "bound": "mfma", "achieved": wflops / wsec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": wflops / wsec / peak,
-                            "avg_launch_ms": wsec * 1e3, "traffic": tr_b, "traffic_source": tr_src})
+            kernels.append(entry("conv3d wgrad 32->16 3x3x3 @%d^3 (decode0.0) + slab reduce, unet_op_conv3d_bwd_weight" % n, wflops,
+                                 n ** 3 * (32 + 16) * esz + 27 * 32 * 16 * 4, wsec, "wgrad_kernel_traffic"))
             out["roofline_kernels"] = kernels
             if "roofline" not in out:
-                out["roofline"] = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms")}
+                out["roofline"] = dict(kernels[0])
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(out), flush=True)

@@ -1189,7 +1189,7 @@ template <int BZ, int BY, int BX> static int launch_small(const MfmaConvArgs& a0
     return tiles;
 }
 static int launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
-    if (CK == 32) { const int gz = launch_conv_z(a, s); if (gz) return gz; }
+    if (CK == 32) { int gz = launch_conv_z32(a, s); if (gz) return gz; gz = launch_conv_z(a, s); if (gz) return gz; }
     else { const int gz = launch_conv_z16(a, s); if (gz) return gz; }
     Tile t = tile_s1k3(a.g, CK);
     if (CK == 32 && small_s1k3(a.g, CK)) return t.bx == 8 ? launch_small<2, 4, 8>(a, s) : launch_small<4, 4, 4>(a, s);

@@ -263,6 +263,230 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pipeline for a single 32-channel chunk (Cin = 32: 32->16 at full resolution -- the forward's heaviest launch -- and the
+// 32->32 layers one level down, forward and dgrad; one 16-row tile per block, blockIdx.y = row tile).  K = 32 is one tap: nine
+// k-steps per kz, 27 filter fragments in registers.  A wave's two m-tiles are consecutive rows, so tap ky of row 2w+1 reads the
+// patch of tap ky+1 of row 2w: 12 fragment reads (4 rows x 3 kx) feed 54 MFMAs.  64-B voxels: the 16-B channel groups of a voxel
+// are stored XOR-ed with bit 2 of the voxel's linear index (conflict-free ds_read_b128 for 16 consecutive voxels at any offset);
+// the LDS image of an LDS-DMA is lane-linear, so the swizzle is applied to the SOURCE address (which channel group a lane fetches).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) k_mfma_conv_z32(MfmaConvArgs a, ZWork zw) {
+    constexpr int BY = 8, BX = 16, HY = BY + 2, HX = BX + 2, PLANE_B = HY * HX * 64;
+    constexpr int UNITS = HY * HX * 4, UPW = UNITS / 4, ITERS = 3;     // 720 units; a wave moves 180: pieces of 64, 64 and 52 lanes
+    constexpr int NBUF = 6, PF = 5;
+    static_assert(UPW == 180 && UPW % 4 == 0 && NBUF % 3 == 0 && NBUF >= PF + 1, "unit split / ring");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
+    const int nt0 = blockIdx.y, NTT = g.Cout / 16, C0 = a.src[0].C;
+    const bf16x8* wp = (const bf16x8*)a.w;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    bf16x8 wf[27];
+#pragma unroll
+    for (int ks = 0; ks < 27; ++ks) wf[ks] = wp[((size_t)ks * NTT + nt0) * 64 + lane];
+    // patch addresses: plane rows 2 wave + R (R = 0..3), kx = 0..2
+    int mb[4][3];
+#pragma unroll
+    for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hv = (2 * wave + R) * HX + j + kx;
+            mb[R][kx] = hv * 64 + ((gq ^ (((hv >> 2) & 1) << 1)) << 4);
+        }
+    // staging units: unit u = (voxel hv, slot); slot holds channel group slot ^ swz(hv)
+    int uyx[ITERS];
+    bool uact[ITERS];
+    unsigned upiece[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int u = wave * UPW + it * 64 + lane, hv = u >> 2, hy = hv / HX, hx = hv % HX;
+        uact[it] = it * 64 + lane < UPW;
+        uyx[it] = hy | (hx << 8) | ((((u & 3) ^ (((hv >> 2) & 1) << 1))) << 16);       // hy, hx, channel group of the unit
+        upiece[it] = (unsigned)__builtin_amdgcn_readfirstlane((wave * UPW + it * 64) * 16);
+    }
+
+    float s1[4], s2[4], b4[4];
+    const int cch = nt0 * 16 + gq * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; b4[r] = a.bias ? a.bias[cch + r] : 0.f; }
+    const int dsel = (a.nout > 1 && nt0 * 16 >= a.outC[0]) ? 1 : 0;
+    char* ob = (char*)(dsel ? a.out[1] : a.out[0]);
+    const int oC = dsel ? a.outC[1] : a.outC[0], oacc = dsel ? a.out_acc[1] : a.out_acc[0], cd = cch - (dsel ? a.outC[0] : 0);
+    const bool ohave = ob != nullptr;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(ob, 0, ob ? (int)((size_t)a.oD * a.oH * a.oW * oC * 2) : 0, 0x00020000);
+    constexpr int OOB = (int)0x80000000;
+
+    const int nitems = zw.cols_x * zw.cols_y * zw.nseg, ncols = zw.cols_x * zw.cols_y;
+    for (int item = xcd_remap(blockIdx.x, gridDim.x); item < nitems; item += gridDim.x) {
+        const int seg = item / ncols, col = item % ncols;
+        const int x0 = (col % zw.cols_x) * BX, y0 = (col / zw.cols_x) * BY;
+        const int zs = seg * zw.zlen, ze = zs + zw.zlen < g.D ? zs + zw.zlen : g.D;
+        bool uok[ITERS];
+        const char* ubase[ITERS];
+        unsigned uvs[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int gy = y0 - 1 + (uyx[it] & 255), gx = x0 - 1 + ((uyx[it] >> 8) & 255), c = (uyx[it] >> 16) * 8;
+            const int sidx = (a.nsrc > 1 && c >= C0) ? 1 : 0;
+            uok[it] = uact[it] && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            uvs[it] = (unsigned)(sidx ? a.src[1].C : C0) * 2;
+            ubase[it] = (const char*)(sidx ? a.src[1].ptr : a.src[0].ptr) + (size_t)(c - (sidx ? C0 : 0)) * 2 + (size_t)(uok[it] ? gy * g.W + gx : 0) * uvs[it];
+        }
+        const size_t hw = (size_t)g.H * g.W;
+        const int rlast = (ze - zs) + 2;
+        // 3 DMA pieces + 2 output stores per wave and step: plane r is awaited with vmcnt(5 PF - 3) (see k_mfma_conv_z16)
+        auto dma = [&](int r, int slot) {
+            const int pz = zs - 1 + r;
+            const bool zin = (unsigned)pz < (unsigned)g.D && r < rlast;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const char* src = (zin && uok[it]) ? ubase[it] + (size_t)pz * hw * uvs[it] : (const char*)g_z16_zero;
+                const unsigned dst = lds0 + (unsigned)slot * PLANE_B + upiece[it];
+                unsigned keep;
+                if (it < 2 || uact[it])
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        };
+        const int ox = x0 + j;
+        bool ook[2];
+        unsigned ooff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = y0 + 2 * wave + i;
+            ook[i] = oy < a.oH && ox < a.oW;
+            ooff[i] = (unsigned)(((((size_t)zs * a.oH + (ook[i] ? oy : 0)) * a.oW + (ook[i] ? ox : 0)) * oC + cd) * 2);
+        }
+        const unsigned oplane = (unsigned)((size_t)a.oH * a.oW * oC * 2);
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        auto compute = [&](int r, auto phc, auto slc) {
+            constexpr int PH = decltype(phc)::value, BQ = decltype(slc)::value;
+            bf16x8 xr[4][3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int R = 0; R < 4; ++R) xr[R][kx] = *(const bf16x8*)(smem + BQ * PLANE_B + mb[R][kx]);
+            __builtin_amdgcn_sched_barrier(0);       // all twelve reads in flight before the first MFMA
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            f32x4& d = acc[(PH - kz + 3) % 3][i];
+                            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kz * 9 + ky * 3 + kx], xr[i + ky][kx],
+                                                                        (kz == 0 && kx == 0 && ky == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : d, 0, 0, 0);
+                        }
+            const int k = r - 3;
+            const bool kin = k >= 0 && zs + k < ze;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const f32x4 d = acc[(PH + 1) % 3][i];
+                const bool ok = kin && ook[i] && ohave;
+                const int off = ok ? (int)(ooff[i] + (unsigned)k * oplane) : OOB;
+                float v0 = d[0] + b4[0], v1 = d[1] + b4[1], v2 = d[2] + b4[2], v3 = d[3] + b4[3];
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                if (oacc) {
+                    const u32x2 old = __builtin_amdgcn_raw_buffer_load_b64(orsrc, off, 0, 0);
+                    v0 += bf_lo(old.x); v1 += bf_hi(old.x); v2 += bf_lo(old.y); v3 += bf_hi(old.y);
+                }
+                u32x2 o;
+                o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                __builtin_amdgcn_raw_buffer_store_b64(o, orsrc, off, 0, 0);
+                const float r0 = ok ? bf_lo(o.x) : 0.f, r1 = ok ? bf_hi(o.x) : 0.f, r2 = ok ? bf_lo(o.y) : 0.f, r3 = ok ? bf_hi(o.y) : 0.f;
+                s1[0] += r0; s1[1] += r1; s1[2] += r2; s1[3] += r3;
+                s2[0] = fmaf(r0, r0, s2[0]); s2[1] = fmaf(r1, r1, s2[1]); s2[2] = fmaf(r2, r2, s2[2]); s2[3] = fmaf(r3, r3, s2[3]);
+            }
+        };
+        auto step = [&](int r, auto phc, auto slc) {
+            constexpr int SL = decltype(slc)::value;
+            static_assert(PF == 5, "vmcnt below = 5 PF - 3");
+            asm volatile("s_waitcnt vmcnt(22)\n\ts_barrier" ::: "memory");
+            dma(r - 1 + PF, (SL + PF) % NBUF);
+            compute(r, phc, slc);
+        };
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            dma(r, r);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, orsrc, OOB + 8 * (r * 2 + i), 0, 0);
+            }
+        }
+        for (int r = 1; r <= rlast; r += 6) {
+            step(r, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            if (r + 1 > rlast) break;
+            step(r + 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+            if (r + 2 > rlast) break;
+            step(r + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            if (r + 3 > rlast) break;
+            step(r + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+            if (r + 4 > rlast) break;
+            step(r + 4, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            if (r + 5 > rlast) break;
+            step(r + 5, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (a.stats) {
+        float* red = (float*)smem;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float u = s1[r], v = s2[r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { u += __shfl_xor(u, m); v += __shfl_xor(v, m); }
+            if (j == 0) { red[(wave * 16 + gq * 4 + r) * 2] = u; red[(wave * 16 + gq * 4 + r) * 2 + 1] = v; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { u += red[(w * 16 + tid) * 2]; v += red[(w * 16 + tid) * 2 + 1]; }
+            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 0] = u;
+            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 1] = v;
+        }
+    }
+}
+
+int launch_conv_z32(const MfmaConvArgs& a0, hipStream_t s) {
+    const ConvGeom& g = a0.g;
+    static const bool off = getenv("UNET_NO_CONV_Z32") != nullptr;     // falls back to k_mfma_conv_z (register-staged planes, hand-placed waits)
+    if (off || g.Cin != 32 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
+    for (int k = 0; k < 2; ++k)
+        if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return 0;
+    if (a0.nout > 1 && a0.outC[0] % 16) return 0;
+    for (int k = 0; k < a0.nsrc; ++k) if (a0.src[k].C % 8) return 0;
+    ZWork zw;
+    zw.cols_x = (g.Wo + 15) / 16; zw.cols_y = (g.Ho + 7) / 8;
+    const int cols = zw.cols_x * zw.cols_y, gy = g.Cout / 16;
+    int want = 512 / gy;
+    if (want < 1) want = 1;
+    int nseg = (want + cols - 1) / cols;
+    if (nseg < 1) nseg = 1;
+    int zlen = (g.Do + nseg - 1) / nseg;
+    if (zlen < 4) zlen = 4;
+    nseg = (g.Do + zlen - 1) / zlen;
+    zw.nseg = nseg; zw.zlen = zlen;
+    const int items = cols * nseg;
+    const int gx = items < want ? items : want;
+    constexpr int lds = 6 * 10 * 18 * 64;
+    static std::atomic<uint64_t> attr_done{0};
+    set_max_lds_once(attr_done, (const void*)k_mfma_conv_z32, lds);
+    k_mfma_conv_z32<<<dim3((unsigned)gx, (unsigned)gy), 256, lds, s>>>(a0, zw);
+    return gx;
+}
+
 int launch_conv_z16(const MfmaConvArgs& a0, hipStream_t s) {
     const ConvGeom& g = a0.g;
     static const bool off = getenv("UNET_NO_CONV_Z16") != nullptr;

@@ -70,5 +70,6 @@ struct ZWork { int nseg, zlen, cols_x, cols_y; };
 // sliding window for a single 16-channel chunk (kernels_mfma_conv_z16.hip); returns 0 if the geometry does not qualify, else the
 // number of statistics rows (gridDim.x)
 int launch_conv_z16(const MfmaConvArgs& a, hipStream_t s);
+int launch_conv_z32(const MfmaConvArgs& a, hipStream_t s);     // the same for a single 32-channel chunk
 
 }  // namespace unet
