@@ -558,6 +558,51 @@ struct Exec {
             }
             wz_pending = 0;
         };
+        // weight / bias gradient of op i (its dL/d(raw output) is final), enqueued on sb
+        auto do_wgrad = [&](int i) {
+            const Op& op = g.ops[i];
+            const int t = op.dst;
+            SrcDesc sd[2] = {src(op.src[0]), op.nsrc > 1 ? src(op.src[1]) : SrcDesc()};
+            ConvGeom cg = geom(op);
+            ProfScope pw(i, UNET_PROF_WGRAD, sb);
+            if (op.kind == OP_CONV) {
+                if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
+                    const bool defer = gflat && p.wz_job_of_op[i] >= 0;
+                    launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias],
+                                                 ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                    if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
+                } else if (p.wgrad_mfma[i]) {
+                    const bool defer = gflat && p.wz_job_of_op[i] >= 0;   // slab only: summed by the batched reduce below
+                    launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias],
+                                           ws + (p.wz_off[i] != SIZE_MAX ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                    if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
+                }
+                else if (p.impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
+                    launch_wgrad_f32_mfma(cg, sd, op.nsrc, (const float*)gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+                else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
+                    launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+                else
+                    launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+            } else if (p.wgrad_mfma[i]) {
+                const bool defer = gflat && p.wz_job_of_op[i] >= 0;
+                launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
+                launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
+            } else {
+                launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
+            }
+            static const int wz_every = getenv("UNET_WZ_FLUSH") ? atoi(getenv("UNET_WZ_FLUSH")) : 3;   // experiment knob
+            if (wz_pending >= wz_every) flush_wz(sb);
+        };
+        // The backward starts at full resolution, where the caller's stream is bandwidth-bound, and then spends a long stretch in the
+        // small levels, where it is launch-latency bound and the memory system idles.  The big weight gradients of the decoder's top
+        // levels (everything they read stays in the workspace: each tensor has a gradient buffer of its own) are therefore HELD until
+        // the caller's stream reaches the small levels and run beside those, instead of competing with the top levels' dgrad / norm
+        // kernels for bandwidth.  (UNET_WGRAD_HOLD=0: every gradient as soon as its inputs are final.)
+        static const bool hold_on = !(getenv("UNET_WGRAD_HOLD") && getenv("UNET_WGRAD_HOLD")[0] == '0');
+        const int64_t hold_from = hold_on ? (int64_t)64 * 64 * 64 : INT64_MAX, hold_below = (int64_t)32 * 32 * 32;
+        std::vector<int> held;
+        bool deep_seen = false;
         for (int i = (int)g.ops.size() - 1; i >= op_lo; --i) {
             const Op& op = g.ops[i];
             const bool dry = i >= op_hi;
@@ -594,46 +639,25 @@ struct Exec {
                     ConvGeom cg = geom(op);
                     const float* wd = (const float*)(ws + p.w_dgrad[i]);
                     bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
-                    if (!dry) fork();
-                    if (op.kind == OP_CONV) {
-                        ProfScope* pw = dry ? nullptr : new ProfScope(i, UNET_PROF_WGRAD, sb);
-                        if (dry) {
-                        } else if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
-                            const bool defer = gflat && p.wz_job_of_op[i] >= 0;
-                            launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias],
-                                                         ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
-                            if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
-                        } else if (p.wgrad_mfma[i]) {
-                            const bool defer = gflat && p.wz_job_of_op[i] >= 0;   // slab only: summed by the batched reduce below
-                            launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias],
-                                                   ws + (p.wz_off[i] != SIZE_MAX ? p.wz_off[i] : p.wgrad_off), sb, defer);
-                            if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
+                    // parameter gradients: on the side stream now, or held back (see `held`)
+                    if (!dry) {
+                        const int64_t vox = (int64_t)cg.Do * cg.Ho * cg.Wo;
+                        if (!deep_seen && vox <= hold_below && !held.empty()) {     // the small levels begin: the held launches run beside them
+                            deep_seen = true;
+                            fork();
+                            for (int h : held) do_wgrad(h);
+                            held.clear();
                         }
-                        else if (p.impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
-                            launch_wgrad_f32_mfma(cg, sd, op.nsrc, (const float*)gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
-                        else if (p.impl == UNET_IMPL_AUTO && wgrad_small_supported(cg, op.nsrc))
-                            launch_conv_wgrad_small(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
-                        else
-                            launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
-                        delete pw;
-                        static const int wz_every = getenv("UNET_WZ_FLUSH") ? atoi(getenv("UNET_WZ_FLUSH")) : 3;   // experiment knob
-                        if (wz_pending >= wz_every) flush_wz(sb);
+                        if (!deep_seen && sb != s && vox >= hold_from) held.push_back(i);
+                        else { fork(); do_wgrad(i); }
+                    }
+                    if (op.kind == OP_CONV) {
                         ProfScope pd(i, UNET_PROF_DGRAD, s);
                         if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (!dry && any && p.impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(p.dtype, cg, dg, op.nsrc))
                             launch_conv_f32_mfma_dgrad(cg, (const float*)gptr(t), wd, dg, op.nsrc, s);
                         else if (!dry && (any)) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
-                        ProfScope* pw = dry ? nullptr : new ProfScope(i, UNET_PROF_WGRAD, sb);
-                        if (p.wgrad_mfma[i]) {
-                            const bool defer = gflat && p.wz_job_of_op[i] >= 0;
-                            if (!dry) launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
-                            if (!dry && defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
-                            if (!dry) launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
-                        } else {
-                            if (!dry) launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
-                        }
-                        delete pw;
                         ProfScope pd(i, UNET_PROF_DGRAD, s);
                         if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
                         else if (!dry && (any)) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
@@ -668,6 +692,7 @@ struct Exec {
                 default: break;
             }
         }
+        if (!held.empty()) { fork(); for (int h : held) do_wgrad(h); held.clear(); }
         flush_wz(sb);
         if (sb != s) {   // join: whatever the caller enqueues next (optimizer step, next forward) sees every gradient
             HIP_OK(hipEventRecord(p.ev_join, sb));
