@@ -14,6 +14,7 @@ for f in $SRCS; do
 done
 [ -f ../asm_loads_check_conv_z.json ] || todo="$todo check:kernels_mfma_conv.hip"
 [ -f ../asm_loads_check_wgrad_z.json ] || todo="$todo check:kernels_mfma_wgrad_z.hip"
+[ -f ../asm_loads_check_conv_zdma.json ] || todo="$todo check:kernels_mfma_conv_z16.hip"
 todo_src=$(echo $todo | tr ' ' '\n' | grep -v '^check:' | tr '\n' ' ')
 if [ -n "$(echo $todo_src | tr -d ' ')" ]; then
     echo $todo_src | tr ' ' '\n' | xargs -P 6 -I{} sh -c 'f={}; hipcc '"$FLAGS"' -c "$f" -o build/${f%.*}.o'
@@ -21,7 +22,7 @@ fi
 # k_mfma_conv_z and k_mfma_wgrad_z wait for inline-asm loads with hand-counted vmcnt values: check the emitted code whenever
 # their file was rebuilt (tools/check_asm_loads.py: no scratch, the expected memory operations, no instruction touching a load's
 # registers while it is in flight); the result and the toolchain it was validated with are recorded next to the library
-for pair in conv_z:kernels_mfma_conv wgrad_z:kernels_mfma_wgrad_z; do
+for pair in conv_z:kernels_mfma_conv wgrad_z:kernels_mfma_wgrad_z conv_zdma:kernels_mfma_conv_z16; do
     which=${pair%%:*}; f=${pair##*:}
     case " $todo " in *" $f.hip "*|*" check:$f.hip "*)
         hipcc $FLAGS --cuda-device-only -S $f.hip -o build/$f.s 2>/dev/null

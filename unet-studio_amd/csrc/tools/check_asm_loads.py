@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Post-compile gate for the kernels that wait for inline-assembly loads with hand-counted vmcnt values -- k_mfma_conv_z
 (kernels_mfma_conv.hip) and every instantiation of k_mfma_wgrad_z (kernels_mfma_wgrad_z.hip) -- run by build.sh on the device
-assembly of those files:   check_asm_loads.py conv_z <asm> <json>   |   check_asm_loads.py wgrad_z <asm> <json>
+assembly of those files:   check_asm_loads.py conv_z <asm> <json>   |   check_asm_loads.py wgrad_z <asm> <json>   |   check_asm_loads.py conv_zdma <asm> <json>
+(conv_zdma: k_mfma_conv_z16 / k_mfma_conv_z32 of kernels_mfma_conv_z16.hip, LDS-DMA planes: see scan_dma)
 
 What follows describes the conv_z rules; wgrad_z is checked the same way with its own expectations (per instantiation: the
 inline-asm loads come in groups of NL = loads per step, every hand-placed wait is vmcnt(NL) or vmcnt(0), no compiler-generated
@@ -131,6 +132,73 @@ def scan(body, mode):
     return errors, {"asm_loads": asm_loads, "buffer_store_dwordx2": stores, "hand_waits": waits}
 
 
+def scan_dma(body):
+    """k_mfma_conv_z16 / _z32: planes travel by inline-asm LDS-DMA (global_load_lds_dwordx4, no destination registers) and are awaited
+    with ONE hand-counted value vmcnt(N), N = (P + S) * PF - P for P DMA pieces and S output stores per step, PF planes ahead (younger than a
+    plane's last piece: that step's S stores and PF - 1 whole steps).
+    Checked between consecutive hand-placed waits vmcnt(N): exactly P LDS-DMA pieces and S buffer_store_dwordx2, and no other
+    vector-memory instruction except the buffer_load_dwordx2 of the accumulate path (an extra operation there only makes the
+    count conservative, and the compiler follows it with its own vmcnt(0))."""
+    errors, in_asm = [], False
+    waits, seg, segs = {}, None, []
+    for line in body:
+        t = line.strip()
+        if "#ASMSTART" in t:
+            in_asm = True
+            continue
+        if "#ASMEND" in t:
+            in_asm = False
+            continue
+        if not t or t[0] in ";." or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        op = t.split()[0]
+        if in_asm and op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                waits[n] = waits.get(n, 0) + 1
+                if seg is not None:
+                    segs.append(seg)
+                seg = {"dma": 0, "store": 0, "other": []} if n else None
+            continue
+        if seg is None:
+            continue
+        if seg.get("closed"):
+            continue
+        if (op.startswith("s_cbranch_scc") or op == "s_branch") and seg["store"] >= 2:
+            seg["closed"] = True       # the step's straight-line code ends at the loop-control branch that follows its stores; what the
+            continue                   # layout places behind it (the next item's set-up) runs after the loop and ends in a vmcnt(0)
+        if op.startswith("global_load_lds"):
+            seg["dma"] += 1
+        elif op == "buffer_store_dwordx2":
+            seg["store"] += 1
+        elif op.startswith("scratch_") or ((op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_")) and op != "buffer_load_dwordx2"):
+            seg["other"].append(t)
+    steady = [n for n in waits if n]
+    st = {"hand_waits": waits, "steps_checked": len(segs)}
+    if len(steady) != 1 or not waits.get(0):
+        errors.append("hand-placed waits %s (expected one steady-state value and vmcnt(0))" % waits)
+        return errors, st
+    n = steady[0]
+    shapes = set((g["dma"], g["store"]) for g in segs)
+    for g in segs:
+        if g["other"]:
+            errors.append("vector-memory instruction inside a hand-counted step: %s" % g["other"][0])
+            break
+    if len(shapes) != 1:
+        errors.append("steps differ in their (DMA pieces, stores): %s" % sorted(shapes))
+    else:
+        pcs, sts = next(iter(shapes))
+        st.update({"dma_pieces_per_step": pcs, "stores_per_step": sts})
+        pf = (n + pcs) / float(pcs + sts) if pcs + sts else 0
+        if pcs == 0 or pf != int(pf) or pf < 1:
+            errors.append("vmcnt(%d) is not (P + S) * PF - P for P = %d pieces, S = %d stores" % (n, pcs, sts))
+        else:
+            st["planes_ahead"] = int(pf)
+    return errors, st
+
+
 def main(which, path, out_json=None):
     text = open(path).read()
     ver = subprocess.run(["hipcc", "--version"], capture_output=True, text=True).stdout.strip().split("\n")
@@ -138,6 +206,9 @@ def main(which, path, out_json=None):
     if which == "conv_z":
         bodies = kernel_bodies(text, "k_mfma_conv_zE")
         mode = "consume"
+    elif which == "conv_zdma":
+        bodies = kernel_bodies(text, "k_mfma_conv_z16") + kernel_bodies(text, "k_mfma_conv_z32")
+        mode = "dma"
     else:
         bodies = kernel_bodies(text, "k_mfma_wgrad_zI")
         mode = "retire"
@@ -145,11 +216,17 @@ def main(which, path, out_json=None):
         sys.exit("check_asm_loads: no %s kernel found in %s" % (which, path))
     for sym, body in bodies:
         meta = metadata(text, sym)
-        errors, st = scan(body, mode)
-        for key in (".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size"):
-            if meta.get(key) != 0:
-                errors.append("%s = %s (must be 0)" % (key, meta.get(key)))
-        if which == "conv_z":
+        if mode == "dma":
+            errors, st = scan_dma(body)     # (spills outside the hand-counted steps are harmless here: the steps are checked instruction by instruction)
+            st.update({"asm_loads": st.get("dma_pieces_per_step", 0), "buffer_store_dwordx2": st.get("stores_per_step", 0)})
+        else:
+            errors, st = scan(body, mode)
+            for key in (".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size"):
+                if meta.get(key) != 0:
+                    errors.append("%s = %s (must be 0)" % (key, meta.get(key)))
+        if mode == "dma":
+            pass
+        elif which == "conv_z":
             if st["asm_loads"] != 12:
                 errors.append("inline-asm plane loads: %d (expected 12)" % st["asm_loads"])
             if st["buffer_store_dwordx2"] != 8:
