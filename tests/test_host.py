@@ -119,3 +119,18 @@ def test_plan_op_list_names_every_conv_of_the_default_arch():
         v = o["out_dims"] if o["kind"] == 1 else o["in_dims"]
         fl += 2.0 * (o["ks"] ** 3 if o["kind"] == 1 else 8) * o["cin"] * o["cout"] * v[0] * v[1] * v[2]
     assert abs(fl - p.flops_fwd) < 1e-6 * p.flops_fwd
+
+
+def test_hand_counted_kernels_passed_the_build_time_assembly_check():
+    """k_mfma_conv_z, k_mfma_wgrad_z and the LDS-DMA kernels k_mfma_conv_z16 / _z32 wait for inline-assembly loads with hand-counted
+    vmcnt values; csrc/build.sh runs csrc/tools/check_asm_loads.py on their device assembly and records the result next to the
+    library.  The library that is loaded must be one whose checks all passed."""
+    import glob
+    import json
+    recs = sorted(glob.glob(os.path.join(ROOT, "unet-studio_amd", "asm_loads_check_*.json")))
+    assert {os.path.basename(r) for r in recs} >= {"asm_loads_check_conv_z.json", "asm_loads_check_wgrad_z.json", "asm_loads_check_conv_zdma.json"}
+    for r in recs:
+        d = json.load(open(r))
+        assert d["ok"] and d["kernels"] and all(k["ok"] for k in d["kernels"]), r
+    dma = json.load(open(os.path.join(ROOT, "unet-studio_amd", "asm_loads_check_conv_zdma.json")))
+    assert {k["planes_ahead"] for k in dma["kernels"]} == {5}

@@ -391,6 +391,10 @@ static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c) {
     else if (cat % 2 == 0) { c.pa = 2; c.pb = 1; c.wk = 4; }
     else if (cbt % 2 == 0) { c.pa = 1; c.pb = 2; c.wk = 4; }
     else { c.pa = 1; c.pb = 1; c.wk = 4; }
+    // at 32^3 a 2x2-pair block leaves 128 blocks for the chip (4 footprint columns x 8 segments x 4 pair groups); single pairs give 512
+    // (step 3.22 -> 3.19 ms; at 64^3 no difference).  UNET_WZ_P11 = voxel count at or below which single pairs are used.
+    static const int p11_vox = getenv("UNET_WZ_P11") ? atoi(getenv("UNET_WZ_P11")) : 32768;
+    if (p11_vox > 0 && (int64_t)g.D * g.H * g.W <= (int64_t)p11_vox) { c.pa = 1; c.pb = 1; c.wk = 4; }
     c.by = 2 * c.wk;
     c.cols_x = (g.W + c.bx - 1) / c.bx; c.cols_y = (g.H + c.by - 1) / c.by;
     c.gy = (cat / c.pa) * (cbt / c.pb);
