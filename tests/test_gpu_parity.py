@@ -70,6 +70,8 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     # groups per launch, ragged footprints in y and x, z segments of unequal length, volumes narrower than one 32-voxel row
     (16, 16, (9, 11, 37), 3, 1), (32, 16, (13, 9, 33), 3, 1), (16, 32, (5, 12, 40), 3, 1), (32, 32, (6, 9, 40), 3, 1),
     (64, 32, (8, 8, 24), 3, 1), (48, 16, (4, 10, 70), 3, 1), (16, 16, (40, 8, 32), 3, 1), (32, 64, (11, 5, 29), 3, 1),
+    # ... above 32^3 voxels (at or below, the kernel uses single pairs): the 2x2, 2x1 and 1x2 pair blocks
+    (32, 32, (20, 40, 48), 3, 1), (32, 16, (24, 30, 48), 3, 1), (16, 32, (18, 40, 48), 3, 1),
     # sliding window for a single 16-channel chunk (bf16; forward Cin = 16, dgrad Cout = 16; W >= 12, D >= 8): one and two row tiles,
     # ragged footprints, z segments of unequal length
     (16, 16, (11, 9, 19), 3, 1), (16, 32, (10, 17, 33), 3, 1), (32, 16, (9, 10, 18), 3, 1), (16, 16, (37, 8, 16), 3, 1),
