@@ -65,7 +65,15 @@ def test_two_rank_gpu_step_equals_single_rank(dtype):
     # the two-rank sum adds the micro-step gradients in a different order than the single buffer does: fp32 rounding only
     # (measured: 4 of 74116 parameters differ by more than 1e-5 after three steps, the largest by 1.35e-5 --
     # profiles/dbg_f32_determinism.py; each run by itself is bit-reproducible)
-    tol = 5e-5 if dtype == "fp32" else 1e-4
+    # bf16: after the first update the two configurations' parameters differ by ~1e-8; whether steps 2-3 amplify that depends on
+    # whether one bf16 rounding of an activation / gradient / packed filter flips (4e-3 relative, locally) -- a chaotic quantity, not
+    # an error bound.  Measured with profiles/dbg_bnstats_dist.py (fresh processes): two ranks vs one 1.5e-8 with the norm-backward
+    # statistics as a separate pass, 1.1e-4 (2 of 74116 elements above 1e-4) with the statistics in the dgrad epilogue, while those
+    # two single-rank runs differ from EACH OTHER by 2.3e-4 -- although one backward agrees to 1e-7 relative on the fused layer's
+    # dgamma / dbeta (profiles/dbg_bnstats_grad.py), the fused path is bit-reproducible run to run (profiles/dbg_bnstats_det.py) and
+    # the bucketed backward equals the whole one bit for bit (test_backward_in_buckets_equals_one_backward).  The bound below is the
+    # size of one such flip after three steps at lr 0.05, not a rounding-error budget; rank-to-rank identity above stays exact.
+    tol = 5e-5 if dtype == "fp32" else 5e-4
     assert np.allclose(p0, ref, rtol=tol, atol=tol)
     assert np.allclose(s0, sref, rtol=1e-4, atol=1e-5)
     assert np.allclose(s0, s1)

@@ -9,6 +9,8 @@
 #include <functional>
 #include <stdexcept>
 #include <string>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/unet_hip.h"
@@ -75,6 +77,11 @@ struct unet_plan {
     std::vector<size_t> n_stat, n_coef;      // per norm: 4C / 3C floats
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
     std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
+    std::vector<int> n_consumers;            // per tensor: ops that read it
+    // norm-backward partial rows a dgrad epilogue left in a workspace's partial() for the tensor's view_backward, which may run in a later
+    // unet_backward_part call on the same workspace (the bucketed backward must make the same choices as the whole one): workspace -> {tensor, rows}
+    mutable std::mutex bn_mu;
+    mutable std::unordered_map<const void*, std::pair<int, int>> bn_pending;
     std::vector<char> use_mfma;              // per op: forward runs on the MFMA kernel
     std::vector<char> dgrad_mfma;            // per op: dgrad runs on the MFMA kernel
     std::vector<char> wgrad_mfma;            // per op: wgrad runs on the MFMA kernel
@@ -127,6 +134,10 @@ struct unet_plan {
         auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
         t_off.assign(g.tensors.size(), SIZE_MAX);
         g_off.assign(g.tensors.size(), SIZE_MAX);
+        n_consumers.assign(g.tensors.size(), 0);
+        for (const Op& op : g.ops)
+            for (int k = 0; k < op.nsrc && op.kind != OP_NORM; ++k)     // (a norm op names the tensor it normalises: not a reader of the view)
+                if (op.src[k] >= 0) ++n_consumers[op.src[k]];
         a_off.assign(g.tensors.size(), SIZE_MAX);
         for (size_t i = 0; i < g.tensors.size(); ++i) {
             t_off[i] = take((size_t)g.tensors[i].numel() * elsize);
@@ -497,11 +508,19 @@ struct Exec {
         const Tensor& T = p.g.tensors[t];
         if (T.norm >= 0) {
             const Norm& n = p.g.norms[T.norm];
-            launch_norm_bwd_partial(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), T.act, partial(), s);
-            if (launch_norm_bwd_finalize_apply(p.dtype, partial(), stats_blocks(T.voxels()), T.C, T.voxels(), params[n.gamma], stat(T.norm),
+            // the statistics pass, unless the dgrad that produced this gradient already left its partial rows (bn_rows_tensor == t)
+            int rows = stats_blocks(T.voxels()), have = 0;
+            {
+                std::lock_guard<std::mutex> lk(p.bn_mu);
+                auto it = p.bn_pending.find(ws);
+                if (it != p.bn_pending.end()) { if (it->second.first == t) have = it->second.second; p.bn_pending.erase(it); }
+            }
+            if (have > 0) rows = have;
+            else launch_norm_bwd_partial(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), T.act, partial(), s);
+            if (launch_norm_bwd_finalize_apply(p.dtype, partial(), rows, T.C, T.voxels(), params[n.gamma], stat(T.norm),
                                                coef(T.norm), gparams[n.gamma], gparams[n.beta], gptr(t), tptr(t), T.act, s))
                 return;
-            launch_norm_bwd_finalize(partial(), stats_blocks(T.voxels()), T.C, T.voxels(), params[n.gamma], stat(T.norm), coef(T.norm),
+            launch_norm_bwd_finalize(partial(), rows, T.C, T.voxels(), params[n.gamma], stat(T.norm), coef(T.norm),
                                      gparams[n.gamma], gparams[n.beta], s, p.dtype == UNET_DTYPE_F32);
             launch_norm_bwd_apply(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), coef(T.norm), T.act, s);
         } else if (T.act != ACT_NONE) {
@@ -537,6 +556,7 @@ struct Exec {
             HIP_OK(hipStreamWaitEvent(sb, p.ev_fork, 0));
         };
         if (op_lo < 0) op_lo = 0;
+        if (op_hi >= (int)g.ops.size()) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending.erase(ws); }   // a new backward starts
         // gradients in one flat buffer (both hosts allocate them so): the sliding-window wgrads only write their slabs here and ONE
         // batched reduce at the end of this call adds them all into the gradients
         bool gflat = p.wz_jobs_dev != nullptr;
@@ -653,7 +673,21 @@ struct Exec {
                     }
                     if (op.kind == OP_CONV) {
                         ProfScope pd(i, UNET_PROF_DGRAD, s);
-                        if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        if (!dry && (any && p.dgrad_mfma[i])) {
+                            // The source is a norm layer's view read by this conv alone: its gradient is complete when this dgrad
+                            // has written it, so the statistics pass of that norm's backward (a second read of the gradient and of the
+                            // raw tensor) moves into the dgrad's epilogue where the kernel has one (k_mfma_conv_z16).  The rows wait in
+                            // partial(): the next thing the caller's stream runs is that tensor's view_backward.
+                            const int ts = op.src[0];
+                            const Tensor& Ts = g.tensors[ts];
+                            BnBwdStats bn = {tptr(ts), Ts.norm >= 0 ? stat(Ts.norm) : nullptr, partial(), Ts.act, Ts.C};
+                            const bool can = op.nsrc == 1 && Ts.norm >= 0 && p.n_consumers[ts] == 1 && p.dtype == UNET_DTYPE_BF16;
+                            const int rows = launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s, can ? &bn : nullptr);
+                            if (rows > 0) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending[ws] = {ts, rows}; }
+                            static const bool dbg = getenv("UNET_DEBUG_BNSTATS") != nullptr;
+                            if (dbg) fprintf(stderr, "dgrad of op %d (%s): source tensor %d consumers %d norm %d -> bn rows %d\n", i, op.name.c_str(), ts,
+                                             p.n_consumers[ts], Ts.norm, rows);
+                        }
                         else if (!dry && any && p.impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(p.dtype, cg, dg, op.nsrc))
                             launch_conv_f32_mfma_dgrad(cg, (const float*)gptr(t), wd, dg, op.nsrc, s);
                         else if (!dry && (any)) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);

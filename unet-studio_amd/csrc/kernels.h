@@ -204,7 +204,12 @@ void launch_bias_grad(int dtype, const void* dy, int C, int64_t S, float* db, vo
 // dgrad of a 3x3x3 conv, stride 1 or 2 (g = forward geometry)
 bool mfma_conv_dgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_conv_dgrad_w_bytes(const ConvGeom& g);
-void launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
+// bn (optional): also leave the norm-backward statistics of the destination tensor's view (what launch_norm_bwd_partial computes) in
+// bn->partial; returns the number of partial rows written, 0 when the shape is not served by a kernel with that epilogue (the caller
+// then runs launch_norm_bwd_partial as usual).  Only for a single destination that is written, not accumulated.
+struct BnBwdStats { const void* u; const float* stat; float* partial; int act, C; };
+int launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s,
+                           const BnBwdStats* bn = nullptr);
 // ConvTranspose3d 2x2x2 stride 2: forward (1x1 GEMM + depth-to-space scatter) and dgrad (2x2x2 stride-2 conv of dL/dy)
 bool mfma_convt_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_w_bytes(const ConvGeom& g);

@@ -1288,7 +1288,8 @@ int launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const 
 }
 // dgrad (g = forward geometry).  stride 1: 27-tap conv of dL/dy with the flipped filter.  stride 2: 8-tap conv of
 // dL/dy on the coarse grid producing all 8 output parities at once (rows = 8*Cin), scattered to 2*m + parity.
-void launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s) {
+int launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s,
+                           const BnBwdStats* bn) {
     MfmaConvArgs a = base_args();
     a.src[0].ptr = dy; a.src[0].C = g.Cout;
     a.w = w_mfma_dgrad;
@@ -1297,12 +1298,18 @@ void launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfm
     a.oD = g.D; a.oH = g.H; a.oW = g.W;
     if (g.stride == 1) {
         a.g.Cout = g.Cin; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
+        static const bool no_bn = getenv("UNET_NO_DGRAD_BNSTATS") != nullptr;
+        if (bn && !no_bn && ndst == 1 && dst[0].ptr && !dst[0].accumulate && bn->C == g.Cin && pick_ck(g.Cout, true) == 16 && conv_z16_applies(a)) {
+            a.bn_u = bn->u; a.bn_stat = bn->stat; a.bn_partial = bn->partial; a.bn_act = bn->act; a.bn_C = bn->C;
+            return launch_conv_z16(a, s);
+        }
         launch_s1k3(a, pick_ck(g.Cout, true), s);
     } else {
         a.g.Cout = 8 * g.Cin; a.sc_C = g.Cin;
         a.g.Do = (g.D + 1) / 2; a.g.Ho = (g.H + 1) / 2; a.g.Wo = (g.W + 1) / 2;   // coarse positions m with 2m or 2m+1 inside the volume
         launch_k2sc(a, s);
     }
+    return 0;
 }
 
 // ================= public: ConvTranspose3d 2x2x2 stride 2 =================

@@ -26,12 +26,14 @@ namespace unet {
 // what LDS-DMA lanes outside the volume read (16 B of zeros, L2-resident)
 __device__ __attribute__((aligned(16))) unsigned g_z16_zero[4] = {0u, 0u, 0u, 0u};
 
-template <int NT>
+template <int NT, bool BNS>
 __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork zw) {
     constexpr int BY = 8, BX = 16, HY = BY + 2, HX = BX + 2, PLANE_B = HY * HX * 32;
     // a plane = 360 16-B units, LDS image linear in unit order; wave w moves units [90 w, 90 w + 90): one 64-lane LDS-DMA and one of 26 lanes
     constexpr int UNITS = HY * HX * 2, UPW = UNITS / 4, ITERS = 2;
     constexpr int NBUF = 6, PF = 5;                 // ring of planes in LDS, planes requested ahead (NBUF >= PF + 1)
+    constexpr int UOFF = NBUF * PLANE_B, UTILE_B = BY * BX * 32;      // BNS: ring of raw-tensor tiles (one 64-lane DMA piece per wave)
+    static_assert(UTILE_B == 4 * 64 * 16, "one piece per wave");
     static_assert(UPW == 90 && NBUF % 3 == 0 && NBUF >= PF + 1, "unit split / ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom& g = a.g;
@@ -95,6 +97,19 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
         orsrc[n] = __builtin_amdgcn_make_buffer_rsrc(ob, 0, ob ? (int)((size_t)a.oD * a.oH * a.oW * oC[n] * 2) : 0, 0x00020000);
     }
     constexpr int OOB = (int)0x80000000;
+    // BNS: this lane's four channels of the norm being differentiated, and its unit of a raw-tensor tile (row, x, 8-channel half)
+    float bmean[4], brstd[4], bsc[4], bsh[4];
+    if constexpr (BNS) {
+        static_assert(NT == 1, "one row tile per block");
+        const int cc = nt0 * 16 + gq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bmean[r] = a.bn_stat[cc + r]; brstd[r] = a.bn_stat[a.bn_C + cc + r];
+            bsc[r] = a.bn_stat[2 * a.bn_C + cc + r]; bsh[r] = a.bn_stat[3 * a.bn_C + cc + r];
+        }
+    }
+    const int bu_row = tid >> 5, bu_x = (tid >> 1) & 15;
+    const unsigned bu_piece = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
 
     const int nitems = zw.cols_x * zw.cols_y * zw.nseg;
     // Blocks of one XCD (blockIdx.x % 8) take a contiguous range of items, and items are ordered segment-major: an XCD then owns a
@@ -132,6 +147,16 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
                 if (it == 0 || uact[it])
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+            if constexpr (BNS) {      // the raw-tensor tile of the output plane that completes when plane r is computed on: zs + r - 2
+                const int k = r - 2, oy = y0 + bu_row, oxx = x0 + bu_x;
+                const bool ok = k >= 0 && zs + k < ze && oy < a.oH && oxx < a.oW;
+                const char* src = ok ? (const char*)a.bn_u + ((((size_t)(zs + k) * a.oH + oy) * a.oW + oxx) * a.bn_C + nt0 * 16 + lg * 8) * 2
+                                     : (const char*)g_z16_zero;
+                const unsigned dst = lds0 + UOFF + (unsigned)slot * UTILE_B + bu_piece;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
             }
         };
         // output offsets of this lane's two voxels (rows 2 wave, 2 wave + 1) in plane zs; plane o = zs + k adds k planes
@@ -200,17 +225,30 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
                     o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
                     __builtin_amdgcn_raw_buffer_store_b64(o, orsrc[n], off, 0, 0);
                     const float r0 = ok ? bf_lo(o.x) : 0.f, r1 = ok ? bf_hi(o.x) : 0.f, r2 = ok ? bf_lo(o.y) : 0.f, r3 = ok ? bf_hi(o.y) : 0.f;
-                    s1[n][0] += r0; s1[n][1] += r1; s1[n][2] += r2; s1[n][3] += r3;
-                    s2[n][0] = fmaf(r0, r0, s2[n][0]); s2[n][1] = fmaf(r1, r1, s2[n][1]);
-                    s2[n][2] = fmaf(r2, r2, s2[n][2]); s2[n][3] = fmaf(r3, r3, s2[n][3]);
+                    if constexpr (BNS) {
+                        // k_norm_bwd_stats8's sums from the gradient as it is stored (bf16) and the raw tensor's tile (zeros outside the volume)
+                        const uint2 uu = *(const uint2*)(smem + UOFF + BQ * UTILE_B + ((2 * wave + i) * BX + j) * 32 + gq * 8);
+                        const float uf[4] = {bf_lo(uu.x), bf_hi(uu.x), bf_lo(uu.y), bf_hi(uu.y)}, rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float dv = rr[c] * act_d(fmaf(uf[c], bsc[c], bsh[c]), a.bn_act);
+                            s1[n][c] += dv;
+                            s2[n][c] = fmaf(dv, (uf[c] - bmean[c]) * brstd[c], s2[n][c]);
+                        }
+                    } else {
+                        s1[n][0] += r0; s1[n][1] += r1; s1[n][2] += r2; s1[n][3] += r3;
+                        s2[n][0] = fmaf(r0, r0, s2[n][0]); s2[n][1] = fmaf(r1, r1, s2[n][1]);
+                        s2[n][2] = fmaf(r2, r2, s2[n][2]); s2[n][3] = fmaf(r3, r3, s2[n][3]);
+                    }
                 }
         };
         // step r: wait for plane r - 1, barrier (every wave's pieces have landed; every wave is done with plane r - 2, whose slot
         // plane r - 1 + PF overwrites: NBUF >= PF + 1), request plane r - 1 + PF, compute on plane r - 1.
         auto step = [&](int r, auto phc, auto slc) {
             constexpr int SL = decltype(slc)::value;      // slot of plane r - 1
-            static_assert(PF == 5, "vmcnt below = 4 PF - 2");
-            asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
+            static_assert(PF == 5, "vmcnt below = (P + 2) PF - P, P = 2 pieces (3 with the raw-tensor tile)");
+            if constexpr (BNS) asm volatile("s_waitcnt vmcnt(22)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
             dma(r - 1 + PF, (SL + PF) % NBUF);
             compute(r, phc, slc);
         };
@@ -241,7 +279,9 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // outstanding requests write LDS: let them land before it is reused
-    if (a.stats) {
+    float* const srows = BNS ? a.bn_partial : a.stats;
+    const int srowC = BNS ? a.bn_C : g.Cout;
+    if (srows) {
         float* red = (float*)smem;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -257,8 +297,8 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z16(MfmaConvArgs a, ZWork 
             float u = 0.f, v = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { u += red[((w * NT) * 16 + tid) * 2]; v += red[((w * NT) * 16 + tid) * 2 + 1]; }
-            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 0] = u;
-            a.stats[((size_t)blockIdx.x * g.Cout + nt0 * 16 + tid) * 2 + 1] = v;
+            srows[((size_t)blockIdx.x * srowC + nt0 * 16 + tid) * 2 + 0] = u;
+            srows[((size_t)blockIdx.x * srowC + nt0 * 16 + tid) * 2 + 1] = v;
         }
     }
 }
@@ -487,14 +527,19 @@ int launch_conv_z32(const MfmaConvArgs& a0, hipStream_t s) {
     return gx;
 }
 
-int launch_conv_z16(const MfmaConvArgs& a0, hipStream_t s) {
+bool conv_z16_applies(const MfmaConvArgs& a0) {
     const ConvGeom& g = a0.g;
     static const bool off = getenv("UNET_NO_CONV_Z16") != nullptr;
-    if (off || g.Cin != 16 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
-    if (g.Cout != 16 && g.Cout != 32) return 0;
+    if (off || g.Cin != 16 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return false;
+    if (g.Cout != 16 && g.Cout != 32) return false;
     for (int k = 0; k < 2; ++k)   // outputs are addressed with 31-bit byte offsets through a buffer descriptor
-        if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return 0;
-    if (a0.nout > 1 && a0.outC[0] % 16) return 0;
+        if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return false;
+    if (a0.nout > 1 && a0.outC[0] % 16) return false;
+    return true;
+}
+int launch_conv_z16(const MfmaConvArgs& a0, hipStream_t s) {
+    const ConvGeom& g = a0.g;
+    if (!conv_z16_applies(a0)) return 0;
     ZWork zw;
     zw.cols_x = (g.Wo + 15) / 16; zw.cols_y = (g.Ho + 7) / 8;
     const int cols = zw.cols_x * zw.cols_y;
@@ -510,7 +555,8 @@ int launch_conv_z16(const MfmaConvArgs& a0, hipStream_t s) {
     const int items = cols * nseg;
     const int gx = items < want ? items : want;
     constexpr int lds = 6 * 10 * 18 * 32;
-    k_mfma_conv_z16<1><<<dim3((unsigned)gx, (unsigned)gy), 256, lds, s>>>(a0, zw);
+    if (a0.bn_partial) k_mfma_conv_z16<1, true><<<dim3((unsigned)gx, (unsigned)gy), 256, lds + 6 * 8 * 16 * 32, s>>>(a0, zw);
+    else k_mfma_conv_z16<1, false><<<dim3((unsigned)gx, (unsigned)gy), 256, lds, s>>>(a0, zw);
     return gx;
 }
 

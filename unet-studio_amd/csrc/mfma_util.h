@@ -63,6 +63,13 @@ struct MfmaConvArgs {
     int tiles_x, tiles_y, tiles_z;
     int sc_C;            // SC: destination channels per tap (rows = 8 * sc_C)
     int oD, oH, oW;      // destination volume
+    // dgrad only (k_mfma_conv_z16): norm-backward statistics of the destination tensor's view in the epilogue.  bn_u = the RAW tensor the
+    // gradient belongs to ([voxel][bn_C] bf16), bn_stat = its norm's {mean, rstd, scale, shift} (4 x bn_C floats), bn_act its activation;
+    // bn_partial[gridDim.x][bn_C][2] receives {sum g, sum g * xhat}, g = dL/d(view) * act'(u * scale + shift) (what k_norm_bwd_stats8 computes)
+    const void* bn_u = nullptr;
+    const float* bn_stat = nullptr;
+    float* bn_partial = nullptr;
+    int bn_act = 0, bn_C = 0;
 };
 
 // work split of the sliding-window kernels: (y, x) columns of the footprint x z segments of zlen output planes
@@ -70,6 +77,7 @@ struct ZWork { int nseg, zlen, cols_x, cols_y; };
 // sliding window for a single 16-channel chunk (kernels_mfma_conv_z16.hip); returns 0 if the geometry does not qualify, else the
 // number of statistics rows (gridDim.x)
 int launch_conv_z16(const MfmaConvArgs& a, hipStream_t s);
+bool conv_z16_applies(const MfmaConvArgs& a);               // the geometry test of launch_conv_z16 alone
 int launch_conv_z32(const MfmaConvArgs& a, hipStream_t s);     // the same for a single 32-channel chunk
 
 }  // namespace unet
