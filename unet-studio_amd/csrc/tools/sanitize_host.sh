@@ -16,7 +16,7 @@ for f in graph.cpp engine.cpp comm.cpp; do
     g++ -std=c++17 -fPIC $SAN $HIPINC -Wno-unused-result -c $f -o build/asan/${f%.*}.o
 done
 OBJS="build/asan/graph.o build/asan/engine.o build/asan/comm.o"
-for f in kernels_direct kernels_elem kernels_mfma_conv kernels_mfma_wgrad kernels_mfma_wgrad_z kernels_augment kernels_mfma_f32; do OBJS="$OBJS build/$f.o"; done
+for f in kernels_direct kernels_elem kernels_mfma_conv kernels_mfma_conv_z16 kernels_mfma_wgrad kernels_mfma_wgrad_z kernels_augment kernels_mfma_f32; do OBJS="$OBJS build/$f.o"; done
 g++ -shared -fPIC $SAN -o build/asan/libunet_hip.so $OBJS -L/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lamdhip64 -ldl
 T=$(python3 -c 'import torch, os; print(os.path.dirname(torch.__file__))')
 ABI=$(python3 -c 'import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))')
