@@ -593,24 +593,40 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_small(Wgrad
 // through LDS, blocks through the slab (fixed order everywhere).
 template <int NACC, typename F>
 __device__ __forceinline__ void small_wgrad_epilogue(float (&acc)[NACC], int nchunk, float* sm, float* slab_row, F omap) {
+    // Through LDS, a third of the accumulators at a time: every lane writes its values as [value][lane], a lane then sums one (value,
+    // chunk) over the lanes that own that chunk, the four wave results are added in wave order.  (The first version ran a xor-shuffle
+    // butterfly per accumulator: 6 x 102 ds_bpermute per wave, ~8 us per CU whatever the volume -- the whole cost of the head backward
+    // on the small levels.)  LDS: small_wgrad_lds_bytes(NACC, nchunk).
+    constexpr int VP = (NACC + 2) / 3, PAD = 65;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int m = 32; m >= nchunk; m >>= 1) {   // all NACC shuffles of a step are independent: their latencies overlap
+    float* smw = sm + wave * VP * PAD;
+    float* smx = sm + 4 * VP * PAD;
+    const int nout = VP * nchunk;
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) acc[a] += __shfl_xor(acc[a], m);
-    }
-    if (lane < nchunk) {
+    for (int ps = 0; ps < 3; ++ps) {
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) sm[(wave * nchunk + lane) * NACC + a] = acc[a];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nchunk * NACC; i += 256) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) t += sm[w * nchunk * NACC + i];
-        int o = omap(i / NACC, i % NACC);
-        if (o >= 0) slab_row[o] = t;
+        for (int a = 0; a < VP; ++a)
+            if (ps * VP + a < NACC) smw[a * PAD + lane] = acc[ps * VP + a];
+        __syncthreads();
+        for (int o = lane; o < nout; o += 64) {
+            const int a = o / nchunk, ch = o % nchunk;
+            float r = 0.f;
+            for (int l = ch; l < 64; l += nchunk) r += smw[a * PAD + l];
+            smx[wave * nout + o] = r;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < nout; o += 256) {
+            const int a = o / nchunk, ch = o % nchunk, i = ps * VP + a;
+            if (i < NACC) {
+                const float t = smx[o] + smx[nout + o] + smx[2 * nout + o] + smx[3 * nout + o];
+                const int dst = omap(ch, i);
+                if (dst >= 0) slab_row[dst] = t;
+            }
+        }
+        __syncthreads();
     }
 }
+static inline size_t small_wgrad_lds_bytes(int nacc, int nchunk) { const int vp = (nacc + 2) / 3; return (size_t)(4 * vp * 65 + 4 * vp * nchunk) * 4; }
 
 struct WgradRegArgs {
     ConvGeom g;
@@ -959,7 +975,7 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
             a.lc = ilog2_exact(g.Cin / 16);
             nb = wgrad_reg_blocks((S << a.lc) * 4);
             const int CO = g.Cout <= 2 ? 2 : g.Cout <= 4 ? 4 : g.Cout <= 6 ? 6 : 8;
-            const size_t lds = (size_t)4 * (1 << a.lc) * (CO * 17) * 4;
+            const size_t lds = small_wgrad_lds_bytes(CO * 17, 1 << a.lc);
             switch (CO) {
                 case 2: UNET_DISPATCH(dtype, (k_wgrad_head<T, 2><<<nb, 256, lds, s>>>(a))); break;
                 case 4: UNET_DISPATCH(dtype, (k_wgrad_head<T, 4><<<nb, 256, lds, s>>>(a))); break;
@@ -970,7 +986,7 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
             a.lc = ilog2_exact(g.Cout / 4);
             const int tiles = g.D * ((g.H + FIRST_TY - 1) / FIRST_TY);
             nb = tiles < 512 ? tiles : 512;
-            const size_t l0 = (size_t)3 * (FIRST_TY + 2) * ((g.W + 5) & ~3) * 4, l1 = (size_t)4 * (1 << a.lc) * 112 * 4;
+            const size_t l0 = (size_t)3 * (FIRST_TY + 2) * ((g.W + 5) & ~3) * 4, l1 = small_wgrad_lds_bytes(112, 1 << a.lc);
             const size_t lds = l0 > l1 ? l0 : l1;
             UNET_DISPATCH(dtype, (k_wgrad_first<T><<<nb, 256, lds, s>>>(a)));
         }
@@ -1019,7 +1035,7 @@ void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const flo
     a.slab = dw ? (float*)scratch : nullptr;
     const int CO = head_co(g.Cout);
     const int nb = wgrad_reg_blocks((a.S << a.lc) * 4);   // one (voxel, chunk) item per thread until 512 blocks are reached
-    const size_t l0 = (size_t)CO * g.Cin * 4, l1 = (size_t)4 * (1 << a.lc) * (CO * 17) * 4;
+    const size_t l0 = (size_t)CO * g.Cin * 4, l1 = small_wgrad_lds_bytes(CO * 17, 1 << a.lc);
     UNET_DISPATCH(dtype, (head_launch<T>(true, CO, nb, l0 > l1 ? l0 : l1, a, s)));
     if (dw) slab_reduce2(a.slab, nb, (int64_t)g.Cin * g.Cout + g.Cout, dw, (int64_t)g.Cin * g.Cout, db, s);
 }
