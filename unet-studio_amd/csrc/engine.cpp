@@ -78,6 +78,7 @@ struct unet_plan {
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
     std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
     std::vector<int> n_consumers;            // per tensor: ops that read it
+    std::vector<int> first_consumer;         // per tensor: the lowest op index among them (-1: none) = the LAST to write its gradient in the backward
     // norm-backward partial rows a dgrad epilogue left in a workspace's partial() for the tensor's view_backward, which may run in a later
     // unet_backward_part call on the same workspace (the bucketed backward must make the same choices as the whole one): workspace -> {tensor, rows}
     mutable std::mutex bn_mu;
@@ -135,9 +136,15 @@ struct unet_plan {
         t_off.assign(g.tensors.size(), SIZE_MAX);
         g_off.assign(g.tensors.size(), SIZE_MAX);
         n_consumers.assign(g.tensors.size(), 0);
-        for (const Op& op : g.ops)
+        first_consumer.assign(g.tensors.size(), -1);
+        for (size_t oi = 0; oi < g.ops.size(); ++oi) {
+            const Op& op = g.ops[oi];
             for (int k = 0; k < op.nsrc && op.kind != OP_NORM; ++k)     // (a norm op names the tensor it normalises: not a reader of the view)
-                if (op.src[k] >= 0) ++n_consumers[op.src[k]];
+                if (op.src[k] >= 0) {
+                    ++n_consumers[op.src[k]];
+                    if (first_consumer[op.src[k]] < 0) first_consumer[op.src[k]] = (int)oi;
+                }
+        }
         a_off.assign(g.tensors.size(), SIZE_MAX);
         for (size_t i = 0; i < g.tensors.size(); ++i) {
             t_off[i] = take((size_t)g.tensors[i].numel() * elsize);
@@ -681,6 +688,9 @@ struct Exec {
                             const int ts = op.src[0];
                             const Tensor& Ts = g.tensors[ts];
                             BnBwdStats bn = {tptr(ts), Ts.norm >= 0 ? stat(Ts.norm) : nullptr, partial(), Ts.act, Ts.C};
+                            // (With several consumers the one with the lowest op index writes last -- accumulating -- and would see the complete
+                            // gradient; for the skip tensors that is the stride-2 scatter dgrad, where the epilogue was built and measured:
+                            // +25 us in the dgrad for -27 us of statistics pass, not kept.)
                             const bool can = op.nsrc == 1 && Ts.norm >= 0 && p.n_consumers[ts] == 1 && p.dtype == UNET_DTYPE_BF16;
                             const int rows = launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s, can ? &bn : nullptr);
                             if (rows > 0) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending[ws] = {ts, rows}; }

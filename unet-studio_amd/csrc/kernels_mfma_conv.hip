@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
         // ---- tile epilogue ----
         const int bid = xcd_remap((int)blockIdx.x + k * (int)gridDim.x, nblk);
         const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
-        if constexpr (SC) {
+        if constexpr (SC && KD == 2) {      // (the stride-2 dgrad; conv_trans forward, KD = 1, never accumulates: it keeps the plain loop and 46 VGPRs)
             // scatter kinds that ACCUMULATE (the stride-2 dgrad adds to the skip tensor's gradient): all old values are requested
             // before the first one is used.  In the generic loop below every (m-tile, row tile) is load -> wait -> add -> store, and the
             // compiler cannot move a load above the previous store: eight exposed latencies per tile (77 us against 41 us write-only).
