@@ -198,7 +198,7 @@ def profile_steps(U, trainer, plan, peak, nsteps=3):
     for (op, cat), ms in per.items():
         if cat in ("conv_fwd", "dgrad", "wgrad") and op >= 0 and (best is None or ms > best[2]):
             best = (op, cat, ms)
-    out = {"kernel_ms_by_family": {k: round(v, 4) for k, v in sorted(fam.items())},
+    out = {"per_op": per, "kernel_ms_by_family": {k: round(v, 4) for k, v in sorted(fam.items())},
            "conv_kernel_ms": conv_ms, "conv_mfma_frac": flops / (conv_ms * 1e-3) / peak if conv_ms > 0 else None,
            "profiled_steps": nsteps, "launch_brackets_per_step": len(pr.records) // nsteps}
     if best is not None:
@@ -207,6 +207,58 @@ def profile_steps(U, trainer, plan, peak, nsteps=3):
         out["dominant"] = {"op": o["name"], "pass": best[1], "flops": fl, "ms": best[2], "bytes": op_bytes(o, best[1], 2 if peak == PEAK_BF16 else 4),
                            "share_of_conv_time": best[2] / conv_ms if conv_ms > 0 else None,
                            "shape": "%d->%d k%d s%d @%s" % (o["cin"], o["cout"], o["ks"], o["stride"], "x".join(str(d) for d in o["out_dims"]))}
+    return out
+
+
+STEP_TRAFFIC_FILE = "profiles/step_hbm_traffic.json"   # written by profiles/collect_step_traffic.sh (rocprofv3 --pmc passes over whole steps)
+
+
+def conv_group(o):
+    """the three groups the round-2 review separated: stride-1 convs at >= 32^3 (95 % of the FLOPs), conv_trans + stride-2 convs,
+    stride-1 convs at <= 16^3; the 1x1x1 heads apart"""
+    if o["kind"] == 2 or o["stride"] == 2:
+        return "conv_trans+stride2"
+    if o["ks"] == 1:
+        return "heads"
+    v = o["out_dims"][0] * o["out_dims"][1] * o["out_dims"][2]
+    return "stride1_ge_32^3" if v >= 32 ** 3 else "stride1_le_16^3"
+
+
+def step_roofline(plan, prof_per, ms_per_step, peak, esize, n_params):
+    """`roofline_step`: the whole step against the HBM roofline, and the conv time by group (live per-op profile).
+    algorithmic bytes = every conv / conv_trans operand once per pass (forward, dgrad, wgrad: op_bytes) + the optimizer's six passes
+    over the fp32 parameters (p, g, m read; p, m, g written); norm / activation / loss passes are NOT algorithmic (ideal fusion folds
+    them into the producing kernels).  counter_bytes = the PMC total recorded by profiles/collect_step_traffic.sh, when present."""
+    ops = plan.ops()
+    alg = 0.0
+    first = True
+    for o in ops:
+        if o["kind"] not in (1, 2):
+            continue
+        alg += op_bytes(o, "conv_fwd", esize) + op_bytes(o, "wgrad", esize)
+        if not first:
+            alg += op_bytes(o, "dgrad", esize)   # the first conv's input needs no gradient
+        first = False
+    alg += 6.0 * 4 * n_params
+    groups = {}
+    for (op, cat), ms in prof_per.items():
+        if op < 0 or cat not in ("conv_fwd", "dgrad", "wgrad"):
+            continue
+        g = groups.setdefault(conv_group(ops[op]), {"ms": 0.0, "flops": 0.0})
+        g["ms"] += ms
+        g["flops"] += op_flops(ops[op])
+    tot_fl = sum(g["flops"] for g in groups.values()) or 1.0
+    out = {"algorithmic_bytes": alg, "hbm_frac": alg / (ms_per_step * 1e-3) / PEAK_HBM, "counter_bytes": None, "counter_source": None,
+           "conv_groups": {k: {"ms_per_step": round(g["ms"], 4), "flop_share": round(g["flops"] / tot_fl, 4),
+                               "mfma_frac": round(g["flops"] / (g["ms"] * 1e-3) / peak, 4) if g["ms"] > 0 else None}
+                           for k, g in sorted(groups.items())}}
+    try:
+        with open(os.path.join(ROOT, STEP_TRAFFIC_FILE)) as f:
+            d = json.load(f)
+        out["counter_bytes"] = d.get("hbm_bytes_per_step")
+        out["counter_source"] = "recorded: %s (%s)" % (STEP_TRAFFIC_FILE, d.get("note", "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over whole steps"))
+    except Exception:
+        pass
     return out
 
 
@@ -264,6 +316,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event profile (roofline / conv_mfma_frac)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the single-kernel micro-benchmarks (roofline_kernels)")
+    ap.add_argument("--batch", type=int, default=8, help="the reference's step shape (train.cpp:604-606: batch_size micro-steps per update, "
+                    "train.hpp:12 default 32; SURVEY 8(d) config 3 asks for 8): B micro-steps per GPU per optimizer step, timed AFTER the "
+                    "headline and reported as `batch<B>` inside the same line; 0 = skip")
     # BASELINE.json configs[4] (not the headline line): --size 256 --in-channels 2 --augment --no-cpu-baseline
     ap.add_argument("--in-channels", type=int, default=1)
     ap.add_argument("--augment", action="store_true", help="augment every sample on the GPU inside the timed step (unet_augment_run)")
@@ -326,6 +381,29 @@ def main():
     dt = float(tt)
     loss = float(trainer._stats[0]) / max(1, len(range(rank, world, world)))
 
+    # the reference's own step shape: batch_size micro-steps per update (train.cpp:604-606,759-761), here B per GPU per step.  Clip,
+    # SGD, the filter pack and the all-reduce are paid once per B samples.  Every rank takes part (collectives inside).
+    batch_line = None
+    if a.batch > 0:
+        pb = U.TrainingParam(batch_size=world * a.batch, epoch=param.epoch, learning_rate=0.001)
+        tb = U.Trainer(model, pb, feed, rank, world)
+        bsteps = max(2, min(a.steps, 48 // a.batch))
+        tb.step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(bsteps):
+            tb.step()
+        sync()
+        dtb = time.perf_counter() - t0
+        tb_ = torch.tensor([dtb], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+        dtb = float(tb_)
+        batch_line = {"micro_steps_per_gpu_per_update": a.batch, "global_batch": world * a.batch, "steps": bsteps,
+                      "ms_per_step": dtb / bsteps * 1e3, "ms_per_sample": dtb / bsteps / a.batch * 1e3,
+                      "value": float(n) ** 3 * world * a.batch * bsteps / dtb, "unit": "voxels/s",
+                      "in_flight": int(os.environ.get("UNET_MICRO_IN_FLIGHT", "1")) if hasattr(tb, "in_flight") else 1}
+
     if rank == 0:
         plan = model.plan_for((n, n, n))
         vox = float(n) ** 3 * world * a.steps
@@ -346,12 +424,16 @@ def main():
             "last_loss": loss,
         }
         kernels = []
+        if a.batch > 0:
+            out["batch%d" % a.batch] = batch_line
         if world == 1 and not a.no_profile:
             # (ranks > 1 would need the other ranks to join the profiled steps' collectives: the profile is a single-GPU measurement)
             prof = profile_steps(U, trainer, plan, peak)
             out["conv_mfma_frac"] = prof["conv_mfma_frac"]
             out["conv_kernel_ms_per_step"] = prof["conv_kernel_ms"]
             out["kernel_ms_by_family"] = prof["kernel_ms_by_family"]
+            out["roofline_step"] = step_roofline(plan, prof["per_op"], out["ms_per_step"], peak, 2 if a.dtype == "bf16" else 4,
+                                                 int(model.flat_params.numel()))
             d = prof.get("dominant")
             if d:
                 # the roofline that binds this launch: the longer of (algorithmic FLOPs / dense MFMA peak) and (algorithmic bytes / HBM peak)

@@ -114,6 +114,13 @@ public: // ---- engine side (not in the reference) ----
     // fused micro-step pieces (train.cpp:634-706 and 759-766 without autograd), optional for callers
     torch::Tensor loss_and_backward(torch::Tensor input, torch::Tensor target_int64, bool ce, bool dice, bool mse, int collapse_before = 0);
     void sgd_step(float lr, float grad_scale, float clip_norm = 12.0f);
+    // Resume path (train.cpp:787, :945-957).  The momentum of the fused update and the momentum_buffer tensors in *optimizer's state
+    // are the same memory once bind_optimizer_state() has run (sgd_step / save_optimizer / load_optimizer call it), so
+    // torch::save(*optimizer, path) and torch::load(*optimizer, path) + bind_optimizer_state() work as train.cpp writes them;
+    // save_optimizer / load_optimizer are those two calls with the binding included (false + error_msg on failure).
+    void bind_optimizer_state(void);
+    bool save_optimizer(const std::string& file_name);
+    bool load_optimizer(const std::string& file_name);
     // Data parallel over RCCL (one process per GPU; unet_hip.h unet_comm_*).  With a communicator attached:
     //   broadcast_parameters(0)   once at start             replaces  other_models[i]->copy_from(*model)   train.cpp:573-579
     //   allreduce_gradients()     after the micro-steps     replaces  model->add_gradient_from(*replica)   train.cpp:756-757
@@ -121,6 +128,7 @@ public: // ---- engine side (not in the reference) ----
     //   the backward; allreduce_gradients() then only reduces what is left and joins.  Every rank runs the same sgd_step.
     void attach_comm(struct unet_comm* comm) { comm_ = comm; reduced_from_ = -1; }
     void broadcast_parameters(int root = 0);
+    void broadcast_buffers(int root = 0);  // BatchNorm running statistics follow the root (copy_from, unet.cpp:207-215); allreduce_gradients() does it each step
     void allreduce_gradients(void);
     torch::Tensor loss_and_backward_overlapped(torch::Tensor input, torch::Tensor target_int64, bool ce, bool dice, bool mse, int collapse_before = 0);
 private:

@@ -99,6 +99,10 @@ int unet_profile_end(int max_records, int* op_index, int* category, float* ms, i
  * (NULL entries are skipped).  mode: 0 = eval (bnorm uses running stats: train.cpp:834-840, and after
  * prepare_for_inference y = gamma*x+beta), 1 = train (batch statistics, running stats updated).
  * workspace: unet_plan_workspace_bytes() bytes; after a mode-1 forward it holds what backward needs. */
+/* mode 1 | UNET_MODE_PACKS_CURRENT: as mode 1, and the caller asserts that the filter packs this workspace holds are current -- i.e. a
+ * mode-1 forward has run on THIS workspace since the parameters last changed (micro-steps 2..batch_size of one optimizer step,
+ * train.cpp:604-606: the parameters only change at :765).  The engine then skips the repack of the bf16 filter images. */
+#define UNET_MODE_PACKS_CURRENT 2
 int unet_forward(const unet_plan* plan, const float* const* params, float* const* buffers, const float* x,
                  float* const* outs, void* workspace, int mode, void* stream);
 
@@ -135,6 +139,10 @@ int unet_loss(const unet_plan* plan, const float* const* outs, const int64_t* ta
 int unet_forward_loss(const unet_plan* plan, const float* const* params, float* const* buffers, const float* x, float* const* outs,
                       const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
                       void* loss_scratch, void* workspace, void* stream);
+/* the same with the forward's mode spelled out: 1, or 1 | UNET_MODE_PACKS_CURRENT */
+int unet_forward_loss_mode(const unet_plan* plan, const float* const* params, float* const* buffers, const float* x, float* const* outs,
+                           const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
+                           void* loss_scratch, void* workspace, int mode, void* stream);
 
 /* step epilogue over flat buffers (train.cpp:759-766 + SGD(momentum, nesterov, weight decay) of
  * unet.cpp:254-275): g *= grad_scale (1/batch_size); coef = min(1, clip_norm/(||g||+1e-6));

@@ -4,6 +4,9 @@
 #include "unet.hpp"
 #include "unet_hip.h"
 #include <c10/hip/HIPCachingAllocator.h>
+#include <c10/hip/HIPStream.h>
+#include <unistd.h>
+#include <cstdio>
 #include <atomic>
 #include <iostream>
 #include <thread>
@@ -186,6 +189,140 @@ int main(int argc, char** argv) {
         REQUIRE(torch::equal(a->flat_params, b->flat_params), "parameters with a one-rank communicator differ from the no-collective run");
         b->attach_comm(nullptr);
         REQUIRE(unet_comm_destroy(comm) == 0, "unet_comm_destroy");
+    }
+    // ---- the reference's own multi-GPU model: ONE process, one communicator per device created together, collectives issued as a
+    // group from one thread (train.cpp:592-600 starts a std::thread per GPU; :756-757 / :573-579 are the reduce and the broadcast).
+    // The test box has one GPU, so n = 1 on device 0: unet_comm_create_all + unet_allreduce_grads_all + broadcast + join must leave a
+    // step bit-identical to the run without any collective, and null entries are rejected before RCCL sees them. ----
+    {
+        int devs[1] = {0};
+        unet_comm* comms[1] = {nullptr};
+        REQUIRE(unet_comm_create_all(1, devs, comms) == 0 && comms[0], std::string("unet_comm_create_all: ") + unet_last_error());
+        int rk = -1, wd = -1;
+        REQUIRE(unet_comm_rank(comms[0], &rk, &wd) == 0 && rk == 0 && wd == 1, "unet_comm_rank of a create_all communicator");
+        UNet3d a(1, 3, arch), b(1, 3, arch);
+        a->engine_dtype = b->engine_dtype = model->engine_dtype;
+        a->to(dev); b->to(dev);
+        b->copy_from(*a);
+        a->train(); b->train();
+        auto xd = x.to(dev);
+        auto tgt = torch::randint(0, 3, {1, 12, 16, 20}, torch::TensorOptions().dtype(torch::kLong).device(dev));
+        void* st = (void*)c10::hip::getCurrentHIPStream(0).stream();
+        {   // broadcast of the parameters from "rank" 0 (train.cpp:573-579), then join
+            REQUIRE(unet_comm_broadcast(comms[0], b->flat_params.data_ptr<float>(), b->flat_params.numel(), 0, st) == 0, unet_last_error());
+            REQUIRE(unet_comm_join(comms[0], st) == 0, unet_last_error());
+        }
+        for (int stp = 0; stp < 2; ++stp) {
+            auto la = a->loss_and_backward(xd, tgt, true, true, true);
+            a->sgd_step(0.01f, 1.0f);
+            auto lb = b->loss_and_backward(xd, tgt, true, true, true);
+            float* flats[1] = {b->flat_grads.data_ptr<float>()};
+            void* streams[1] = {st};
+            REQUIRE(unet_allreduce_grads_all(comms, 1, flats, 0, b->flat_grads.numel(), streams) == 0, std::string("unet_allreduce_grads_all: ") + unet_last_error());
+            REQUIRE(unet_comm_join(comms[0], st) == 0, unet_last_error());
+            b->sgd_step(0.01f, 1.0f);
+            REQUIRE(torch::equal(la, lb), "losses with the in-process communicator group");
+        }
+        torch::cuda::synchronize();
+        REQUIRE(torch::equal(a->flat_params, b->flat_params), "parameters with the in-process communicator group differ from the no-collective run");
+        {   // a null communicator / buffer in the group is an argument error, not a crash inside RCCL
+            unet_comm* bad[1] = {nullptr};
+            float* flats[1] = {b->flat_grads.data_ptr<float>()};
+            void* streams[1] = {st};
+            REQUIRE(unet_allreduce_grads_all(bad, 1, flats, 0, 16, streams) != 0, "null communicator accepted");
+            float* nof[1] = {nullptr};
+            REQUIRE(unet_allreduce_grads_all(comms, 1, nof, 0, 16, streams) != 0, "null buffer accepted");
+        }
+        REQUIRE(unet_comm_destroy(comms[0]) == 0, "unet_comm_destroy");
+    }
+    // ---- two replicas driven by two host threads at once (train.cpp:592-600: a std::thread per GPU, each on its own replica; here
+    // both replicas live on the one device): thread B runs forward + backward micro-steps on `rep` while the main thread trains
+    // `root`; then the reduce-to-root and the broadcast of train.cpp:756-757,573-579.  The sum must equal the two gradients computed
+    // one after the other, bit for bit (the engine's reductions have a fixed order; the streams differ per thread). ----
+    {
+        UNet3d root(1, 3, arch), rep(1, 3, arch), solo(1, 3, arch);
+        for (auto* m : {&root, &rep, &solo}) { (*m)->engine_dtype = model->engine_dtype; (*m)->to(dev); (*m)->train(); }
+        rep->copy_from(*root); solo->copy_from(*root);
+        auto xa = x.to(dev), xb = torch::rand({1, 1, 12, 16, 20}).to(dev);
+        auto ta = torch::randint(0, 3, {1, 12, 16, 20}, torch::TensorOptions().dtype(torch::kLong).device(dev));
+        auto tb = torch::randint(0, 3, {1, 12, 16, 20}, torch::TensorOptions().dtype(torch::kLong).device(dev));
+        torch::cuda::synchronize();
+        std::atomic<int> failures{0};
+        for (int stp = 0; stp < 3; ++stp) {
+            std::thread tb_thread([&]() {
+                try {
+                    // a thread's own stream, as a replica on another GPU would have (the current stream is per thread; the main thread
+                    // synchronises the device after the join)
+                    c10::hip::setCurrentHIPStream(c10::hip::getStreamFromPool(false, 0));
+                    rep->loss_and_backward(xb, tb, true, true, true);
+                } catch (const std::exception& e) { std::cerr << e.what() << std::endl; ++failures; }
+            });
+            root->loss_and_backward(xa, ta, true, true, true);
+            tb_thread.join();
+            torch::cuda::synchronize();
+            root->add_gradient_from(*rep);          // train.cpp:756-757
+            rep->flat_grads.zero_();
+            root->sgd_step(0.01f, 0.5f);
+            rep->copy_from(*root);                  // train.cpp:573-579
+            // the same step on one model, serially
+            solo->loss_and_backward(xa, ta, true, true, true);
+            auto ga = solo->flat_grads.clone();
+            solo->flat_grads.zero_();
+            solo->loss_and_backward(xb, tb, true, true, true);
+            solo->flat_grads.copy_(ga + solo->flat_grads);
+            solo->sgd_step(0.01f, 0.5f);
+        }
+        torch::cuda::synchronize();
+        REQUIRE(failures == 0, "replica thread threw");
+        REQUIRE(torch::equal(root->flat_params, solo->flat_params), "two replicas on two threads differ from the serial run");
+        REQUIRE(torch::equal(root->flat_params, rep->flat_params), "copy_from after the step");
+    }
+    // ---- resume (train.cpp:787: torch::save(*optimizer, path + ".opt"); :945-957: torch::load on restart): two steps, checkpoint
+    // (network file + optimizer), a fresh model that loads both, two more steps == four uninterrupted steps, bit for bit ----
+    {
+        UNet3d a(1, 3, arch), b(1, 3, arch);
+        a->engine_dtype = b->engine_dtype = model->engine_dtype;
+        a->to(dev); b->to(dev);
+        b->copy_from(*a);
+        a->train(); b->train();
+        a->create_optimizer(0.01f); b->create_optimizer(0.01f);
+        auto xd = x.to(dev);
+        auto tgt = torch::randint(0, 3, {1, 12, 16, 20}, torch::TensorOptions().dtype(torch::kLong).device(dev));
+        for (int stp = 0; stp < 4; ++stp) { a->loss_and_backward(xd, tgt, true, true, true); a->sgd_step(0.01f, 1.0f); }
+        for (int stp = 0; stp < 2; ++stp) { b->loss_and_backward(xd, tgt, true, true, true); b->sgd_step(0.01f, 1.0f); }
+        const std::string base = std::string("/tmp/test_unet_hpp_resume_") + (bf16 ? "bf16" : "fp32") + "_" + std::to_string((long long)getpid());
+        REQUIRE(save_to_file(b, (base + ".nz").c_str()), "save_to_file");
+        REQUIRE(b->save_optimizer(base + ".nz.opt"), "save_optimizer: " + b->error_msg);
+        UNet3d c;
+        REQUIRE(load_from_file(c, (base + ".nz").c_str()), "load_from_file");
+        c->engine_dtype = model->engine_dtype;
+        c->to(dev); c->train();
+        c->create_optimizer(0.01f);
+        REQUIRE(c->load_optimizer(base + ".nz.opt"), "load_optimizer: " + c->error_msg);
+        for (int stp = 0; stp < 2; ++stp) { c->loss_and_backward(xd, tgt, true, true, true); c->sgd_step(0.01f, 1.0f); }
+        torch::cuda::synchronize();
+        REQUIRE(torch::equal(a->flat_params, c->flat_params), "resumed run differs from the uninterrupted one");
+        // and WITHOUT the optimizer file the momentum is lost: the test would not notice a save that wrote nothing otherwise
+        UNet3d d;
+        REQUIRE(load_from_file(d, (base + ".nz").c_str()), "load_from_file (2)");
+        d->engine_dtype = model->engine_dtype;
+        d->to(dev); d->train(); d->create_optimizer(0.01f);
+        for (int stp = 0; stp < 2; ++stp) { d->loss_and_backward(xd, tgt, true, true, true); d->sgd_step(0.01f, 1.0f); }
+        torch::cuda::synchronize();
+        REQUIRE(!torch::equal(a->flat_params, d->flat_params), "momentum made no difference: the resume test is vacuous");
+        // the plain calls train.cpp makes work too: torch::save(*optimizer) after a fused step carries the fused momentum
+        torch::save(*(c->optimizer), base + ".2.opt");
+        UNet3d e2(1, 3, arch);
+        e2->engine_dtype = model->engine_dtype;
+        e2->to(dev); e2->train(); e2->create_optimizer(0.01f);
+        torch::load(*(e2->optimizer), base + ".2.opt");
+        e2->bind_optimizer_state();
+        e2->copy_from(*c);
+        c->loss_and_backward(xd, tgt, true, true, true); c->sgd_step(0.01f, 1.0f);
+        e2->loss_and_backward(xd, tgt, true, true, true); e2->sgd_step(0.01f, 1.0f);
+        torch::cuda::synchronize();
+        REQUIRE(torch::equal(c->flat_params, e2->flat_params), "torch::save / torch::load of *optimizer lost the fused momentum");
+        std::remove((base + ".nz").c_str()); std::remove((base + ".nz.opt").c_str()); std::remove((base + ".2.opt").c_str());
     }
     std::cout << model->get_info();
     std::cout << "OK " << (bf16 ? "bf16" : "fp32") << " logits rel " << rel(outs[0], yr) << std::endl;

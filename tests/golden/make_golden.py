@@ -87,6 +87,9 @@ def logit_stride(n, level):
     return st if n > 64 else (4 if level == 0 else 1)
 
 
+GRAD_SAMPLE_STRIDE = 997
+
+
 def default_case(n=64):
     """default architecture (train.cpp:1054-1069), in=1, out=6, weights = module init under manual_seed(0)
     (as the GUI does, mainwindow_training.cpp:253).  Params are 60 MB, so the fixture holds a param checksum,
@@ -108,6 +111,11 @@ def default_case(n=64):
         d["logits_l2_%d" % k] = float(np.sqrt((a.astype(np.float64) ** 2).sum()))
     d["grad_l2"] = np.array([float(p.grad.double().norm()) for p in m.parameters()])
     d["grad_head"] = np.stack([np.pad(p.grad.flatten()[:16].numpy(), (0, max(0, 16 - p.numel()))) for p in m.parameters()])
+    # a strided sample of EVERY parameter gradient (every GRAD_SAMPLE_STRIDE-th element of each flattened tensor, concatenated in
+    # parameters() order) and each tensor's largest magnitude: a wrong-but-norm-preserving gradient (a permuted tap, a transposed
+    # channel pair) changes these although it leaves grad_l2 and the 16 leading elements alone
+    d["grad_sample"] = np.concatenate([p.grad.flatten()[::GRAD_SAMPLE_STRIDE].numpy() for p in m.parameters()])
+    d["grad_absmax"] = np.array([float(p.grad.abs().max()) for p in m.parameters()])
     np.savez_compressed(os.path.join(HERE, "default_arch_%d.npz" % n), **d)
     print("default", n, "loss", d["loss"], "stats", d["stats"])
 

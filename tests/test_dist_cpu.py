@@ -113,7 +113,7 @@ def test_two_rank_step_equals_single_rank():
     steps, batch = 3, 4
     single = {}
     _run(0, 1, 0, steps, batch, single)
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_run, args=(2, _free_port(), steps, batch, out), nprocs=2, join=True)
     p0, s0 = out[0]
@@ -134,7 +134,7 @@ def test_two_ranks_with_uneven_or_missing_samples(batch):
     steps = 2
     single = {}
     _run(0, 1, 0, steps, batch, single)
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_run, args=(2, _free_port(), steps, batch, out), nprocs=2, join=True)
     p0, s0 = out[0]

@@ -42,6 +42,13 @@ def _run(rank, world, port, steps, batch, dtype, out, arch=ARCH, n=N, out_c=4, l
         dist.destroy_process_group()
 
 
+def _manager():
+    """The shared dicts' server process is SPAWNED, never forked: by the time a test runs, pytest's process has initialised the GPU
+    (earlier GPU tests), and a forked copy of such a process must not run HIP destructors or touch the device (round 2: a forked
+    Manager child garbage-collected a Plan and crashed in hipFree)."""
+    return mp.get_context("spawn").Manager()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -54,7 +61,7 @@ def _free_port():
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_two_rank_gpu_step_equals_single_rank(dtype):
     steps, batch = 3, 4
-    mgr = mp.Manager()
+    mgr = _manager()
     single, out = mgr.dict(), mgr.dict()
     mp.spawn(_run, args=(1, 0, steps, batch, dtype, single), nprocs=1, join=True)
     mp.spawn(_run, args=(2, _free_port(), steps, batch, dtype, out), nprocs=2, join=True)
@@ -80,12 +87,36 @@ def test_two_rank_gpu_step_equals_single_rank(dtype):
 
 
 @pytest.mark.timeout(600)
+def test_two_rank_gpu_one_step_bf16_differs_by_summation_order_only():
+    """ONE optimizer step, bf16 engine, batch 4: two ranks (2 micro-steps each, summed by the all-reduce) against one rank (4 micro-steps
+    accumulated in one buffer).  Every micro-step sees the same parameters in both configurations, so each per-sample gradient is
+    bit-identical and only the ORDER of the four-term fp32 sum differs: (g0+g2)+(g1+g3) vs ((g0+g1)+g2)+g3.  The update must
+    therefore agree to fp32 summation noise -- 2e-6 of the largest update -- which a collective that dropped, doubled or mis-scaled a
+    bucket (errors of 1e-1 .. 1) cannot meet.  (The three-step test above is bounded loosely because bf16 roundings flip once the
+    parameters differ at all; this one is the tight bound on the collective path.)"""
+    import unet_studio_amd as U
+    mgr = _manager()
+    single, out = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, 0, 1, 4, "bf16", single), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), 1, 4, "bf16", out), nprocs=2, join=True)
+    p0, s0, _ = out[0]
+    p1, _, _ = out[1]
+    ref, sref, _ = single[0]
+    assert np.array_equal(p0, p1), "ranks diverged"
+    init = U.UNet3d(1, 4, ARCH, device="cuda:0", dtype="bf16", seed=0).flat_params.cpu().numpy()
+    du, dr = p0 - init, ref - init
+    assert float(np.abs(dr).max()) > 1e-4, "the step did not move the parameters"
+    assert float(np.abs(du - dr).max()) <= 2e-6 * float(np.abs(dr).max())
+    assert np.allclose(s0, sref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("batch", [1, 3])
 def test_two_ranks_with_uneven_or_missing_samples(batch):
     """batch 1 leaves rank 1 without a micro-step (train.cpp:581-582: min(gpus, batch_size) threads), batch 3 gives the ranks 2 and 1:
     the collective sequence must be the same on both ranks (no hang, no size mismatch) and the result the single-rank one."""
     steps = 2
-    mgr = mp.Manager()
+    mgr = _manager()
     single, out = mgr.dict(), mgr.dict()
     mp.spawn(_run, args=(1, 0, steps, batch, "fp32", single), nprocs=1, join=True)
     mp.spawn(_run, args=(2, _free_port(), steps, batch, "fp32", out), nprocs=2, join=True)
@@ -98,7 +129,7 @@ def test_two_ranks_with_uneven_or_missing_samples(batch):
 def test_two_rank_bnorm_running_statistics_follow_rank0():
     """copy_from overwrites every replica's BatchNorm buffers with the root's each step (unet.cpp:207-215, train.cpp:573-579):
     after a data-parallel step both ranks hold rank 0's running statistics, so validate() / a checkpoint agree on any rank."""
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     mp.spawn(_run, args=(2, _free_port(), 2, 4, "fp32", out, ARCH_BN), nprocs=2, join=True)
     assert np.array_equal(out[0][0], out[1][0])
@@ -113,7 +144,7 @@ def test_configs3_workload_two_ranks_default_arch_128_bf16():
     """BASELINE configs[3] as far as one device allows: default architecture, 128^3, batch_size 8, bf16, split over two ranks
     (4 micro-steps each, the last one through the bucketed backward with asynchronous all-reduces of the finished buckets).
     Both ranks end identical and within bf16's accumulation-order noise of the single-rank step; losses agree."""
-    mgr = mp.Manager()
+    mgr = _manager()
     single, out = mgr.dict(), mgr.dict()
     kw = ("default", 128, 6, 0.001)
     mp.spawn(_run, args=(1, 0, 1, 8, "bf16", single) + kw, nprocs=1, join=True)

@@ -142,14 +142,17 @@ int unet_comm_create(int rank, int world, const void* id_bytes, int device, unet
 int unet_comm_create_all(int n, const int* devices, unet_comm** out) {
     COMM_TRY({
         if (n < 1 || !devices || !out) throw std::runtime_error("unet_comm_create_all: bad argument");
-        std::vector<ncclComm_t> cs(n);
+        std::vector<ncclComm_t> cs(n, nullptr);
         nccl_ok(rccl().CommInitAll(cs.data(), n, devices), "ncclCommInitAll");
+        // every communicator gets an owner before anything else can throw: a failure half way (stream / event creation on device i)
+        // destroys ALL n RCCL communicators and whatever streams exist, and leaves out[] untouched
+        std::vector<std::unique_ptr<unet_comm>> owned;
         for (int i = 0; i < n; ++i) {
-            unet_comm* c = new unet_comm();
-            c->comm = cs[i]; c->rank = i; c->world = n; c->device = devices[i];
-            make_streams(c);
-            out[i] = c;
+            owned.emplace_back(new unet_comm());
+            owned.back()->comm = cs[i]; owned.back()->rank = i; owned.back()->world = n; owned.back()->device = devices[i];
         }
+        for (int i = 0; i < n; ++i) make_streams(owned[i].get());
+        for (int i = 0; i < n; ++i) out[i] = owned[i].release();
     })
 }
 
@@ -180,6 +183,8 @@ int unet_allreduce_grads(unet_comm* c, float* flat, int64_t elem_lo, int64_t ele
 int unet_allreduce_grads_all(unet_comm* const* comms, int n, float* const* flats, int64_t elem_lo, int64_t elem_hi, void* const* streams) {
     COMM_TRY({
         if (!comms || !flats || !streams || n < 1 || elem_lo < 0 || elem_hi < elem_lo) throw std::runtime_error("unet_allreduce_grads_all: bad argument");
+        for (int i = 0; i < n; ++i)
+            if (!comms[i] || !flats[i]) throw std::runtime_error("unet_allreduce_grads_all: null communicator or buffer at index " + std::to_string(i));
         if (elem_hi == elem_lo) return 0;
         for (int i = 0; i < n; ++i) { DevGuard g(comms[i]->device); fork_from(comms[i], streams[i]); }
         nccl_ok(rccl().GroupStart(), "ncclGroupStart");

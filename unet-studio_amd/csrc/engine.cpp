@@ -3,6 +3,7 @@
 // so concurrent calls on one plan are safe when they use different workspaces (qc.cpp:273-297).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -78,7 +79,6 @@ struct unet_plan {
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
     std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
     std::vector<int> n_consumers;            // per tensor: ops that read it
-    std::vector<int> first_consumer;         // per tensor: the lowest op index among them (-1: none) = the LAST to write its gradient in the backward
     // norm-backward partial rows a dgrad epilogue left in a workspace's partial() for the tensor's view_backward, which may run in a later
     // unet_backward_part call on the same workspace (the bucketed backward must make the same choices as the whole one): workspace -> {tensor, rows}
     mutable std::mutex bn_mu;
@@ -109,7 +109,12 @@ struct unet_plan {
     // backward side stream: the parameter-gradient kernels (wgrad, its reduce, bias grad) of a layer run beside the
     // dgrad -> norm-backward chain of the next one (they only share read-only inputs); forked / joined with events
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
+    // the training forward packs the filters in two launches on the side stream: the units of the ops before pack_split_op (the
+    // encoder's top levels: a few hundred KB) and the rest (the deep levels and the decoder: ~70 MB); the second is only awaited
+    // by the first op that reads one of its packs, ~0.3 ms into the forward
+    int pack_split_op = 0;
+    int64_t pack_split_blocks = 0;
     size_t head_off = 0;                     // scratch of the fused head backward (stays on the main stream)
 
     ~unet_plan() {
@@ -118,6 +123,7 @@ struct unet_plan {
         if (jobs_dev) (void)hipFree(jobs_dev);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_pack) (void)hipEventDestroy(ev_pack);
         if (side) (void)hipStreamDestroy(side);
     }
 
@@ -136,14 +142,10 @@ struct unet_plan {
         t_off.assign(g.tensors.size(), SIZE_MAX);
         g_off.assign(g.tensors.size(), SIZE_MAX);
         n_consumers.assign(g.tensors.size(), 0);
-        first_consumer.assign(g.tensors.size(), -1);
         for (size_t oi = 0; oi < g.ops.size(); ++oi) {
             const Op& op = g.ops[oi];
             for (int k = 0; k < op.nsrc && op.kind != OP_NORM; ++k)     // (a norm op names the tensor it normalises: not a reader of the view)
-                if (op.src[k] >= 0) {
-                    ++n_consumers[op.src[k]];
-                    if (first_consumer[op.src[k]] < 0) first_consumer[op.src[k]] = (int)oi;
-                }
+                if (op.src[k] >= 0) ++n_consumers[op.src[k]];
         }
         a_off.assign(g.tensors.size(), SIZE_MAX);
         for (size_t i = 0; i < g.tensors.size(); ++i) {
@@ -267,8 +269,8 @@ struct unet_plan {
             SrcDesc sd[2];
             for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
             if (op.kind == OP_CONV && conv_first_wgrad_mfma_supported(dtype, cg, sd, op.nsrc)) wz_off[i] = take(conv_first_wgrad_mfma_scratch_bytes(cg));
-            else if (op.kind == OP_CONV && wgrad_mfma[i]) wz_off[i] = take(mfma_wgrad_scratch_bytes(cg));
-            else if (op.kind == OP_CONVT && wgrad_mfma[i]) wz_off[i] = take(mfma_convt_wgrad_scratch_bytes(cg));
+            else if (op.kind == OP_CONV && wgrad_mfma[i]) { if (!mfma_conv_wgrad_direct(cg)) wz_off[i] = take(mfma_wgrad_scratch_bytes(cg)); }
+            else if (op.kind == OP_CONVT && wgrad_mfma[i]) { if (!mfma_convt_wgrad_direct(cg)) wz_off[i] = take(mfma_convt_wgrad_scratch_bytes(cg)); }
         }
         ws_bytes = off;
         // batched filter pack: one job per MFMA filter pack, sources as offsets into a flat parameter buffer
@@ -306,9 +308,12 @@ struct unet_plan {
         }
         pack_jobs.clear();
         pack_blocks = 0;
+        pack_split_op = -1; pack_split_blocks = 0;
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             if ((op.kind != OP_CONV && op.kind != OP_CONVT) || !use_mfma[i]) continue;
+            // first matrix-core op whose output is 16^3 voxels or smaller: everything from here on goes into the second pack launch
+            if (pack_split_op < 0 && g.tensors[op.dst].voxels() <= (int64_t)16 * 16 * 16) { pack_split_op = (int)i; pack_split_blocks = pack_blocks; }
             PackJob jb[2];
             int n = op.kind == OP_CONV ? mfma_conv_pack_jobs(op_geom_of(op), dgrad_mfma[i] != 0, jb) : mfma_convt_pack_jobs(op_geom_of(op), jb);
             for (int k = 0; k < n; ++k) {
@@ -368,10 +373,15 @@ struct Exec {
     void forward(const float* const* params, float* const* buffers, const float* x, float* const* outs, int mode,
                  const std::function<void(int)>* on_head = nullptr) {
         const Graph& g = p.g;
+        // UNET_MODE_PACKS_CURRENT: the filter packs this workspace holds were made from these parameter values (an earlier mode-1
+        // forward on it since the last update): micro-steps 2..batch_size of an optimizer step skip the ~0.1 ms / 190 MB repack
+        const bool packs_current = (mode & UNET_MODE_PACKS_CURRENT) != 0;
+        mode &= 1;
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
         // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
-        bool packed = false, pack_pending = false;
-        if (p.jobs_dev) {
+        bool packed = false, pack_pending = false, pack2_pending = false;
+        if (p.jobs_dev && packs_current) packed = true;
+        else if (p.jobs_dev) {
             bool flat = true;
             for (size_t i = 0; i < g.params.size() && flat; ++i) flat = params[i] == params[0] + p.p_off[i];
             if (flat) {
@@ -382,8 +392,18 @@ struct Exec {
                 if (mode == 1 && p.side && !no_side && !g_prof) {
                     HIP_OK(hipEventRecord(p.ev_fork, s));
                     HIP_OK(hipStreamWaitEvent(p.side, p.ev_fork, 0));
-                    launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, p.side);
-                    HIP_OK(hipEventRecord(p.ev_join, p.side));
+                    static const bool one_pack = getenv("UNET_PACK_ONE_LAUNCH") != nullptr;
+                    if (p.pack_split_op > 0 && p.pack_split_blocks > 0 && !one_pack) {
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_split_blocks, p.side);
+                        HIP_OK(hipEventRecord(p.ev_join, p.side));
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks - p.pack_split_blocks, p.side,
+                                                 p.pack_split_blocks);
+                        HIP_OK(hipEventRecord(p.ev_pack, p.side));
+                        pack2_pending = true;
+                    } else {
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, p.side);
+                        HIP_OK(hipEventRecord(p.ev_join, p.side));
+                    }
                     pack_pending = true;
                 } else {
                     ProfScope ps(-1, UNET_PROF_OTHER, s);
@@ -392,8 +412,9 @@ struct Exec {
                 packed = true;
             }
         }
-        auto need_packs = [&]() {
+        auto need_packs = [&](int op_index = 1 << 30) {
             if (pack_pending) { HIP_OK(hipStreamWaitEvent(s, p.ev_join, 0)); pack_pending = false; }
+            if (pack2_pending && op_index >= p.pack_split_op) { HIP_OK(hipStreamWaitEvent(s, p.ev_pack, 0)); pack2_pending = false; }
         };
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
@@ -409,7 +430,7 @@ struct Exec {
                     ConvGeom cg = geom(op);
                     float* wf = (float*)(ws + p.w_fwd[i]);
                     float* wd = (float*)(ws + p.w_dgrad[i]);
-                    if (p.use_mfma[i]) need_packs();
+                    if (p.use_mfma[i]) need_packs((int)i);
                     if (op.kind == OP_CONV && p.use_mfma[i]) {
                         if (!packed)
                             launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i],
@@ -432,7 +453,7 @@ struct Exec {
                         int rows = launch_conv_first_mfma(cg, sd, params[op.weight], params[op.bias], tptr(op.dst),
                                                           want_stats ? partial() : nullptr, s);
                         if (want_stats) fused_blocks[T.norm] = rows;
-                        if (mode == 1) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                        if (mode == 1 && !packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                     } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level < 0 &&
                                conv_f32_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
                         // fp32 engine: the same IEEE fp32 products and sums as the VALU kernel below, on the fp32 matrix cores
@@ -591,6 +612,7 @@ struct Exec {
             const int t = op.dst;
             SrcDesc sd[2] = {src(op.src[0]), op.nsrc > 1 ? src(op.src[1]) : SrcDesc()};
             ConvGeom cg = geom(op);
+            {   // the op's own bracket closes before flush_wz opens the batched reduce's (they would nest and count the reduce twice)
             ProfScope pw(i, UNET_PROF_WGRAD, sb);
             if (op.kind == OP_CONV) {
                 if (p.impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
@@ -618,6 +640,7 @@ struct Exec {
             } else {
                 launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
             }
+            }
             static const int wz_every = getenv("UNET_WZ_FLUSH") ? atoi(getenv("UNET_WZ_FLUSH")) : 3;   // experiment knob
             if (wz_pending >= wz_every) flush_wz(sb);
         };
@@ -630,6 +653,18 @@ struct Exec {
         const int64_t hold_from = hold_on ? (int64_t)64 * 64 * 64 : INT64_MAX, hold_below = (int64_t)32 * 32 * 32;
         std::vector<int> held;
         bool deep_seen = false;
+        // An event record on the caller's stream is not free: the kernel behind it starts ~6 us late (time line of a step,
+        // profiles/r07_timeline.txt: every dgrad that follows a fork).  The weight gradient of a layer can start any time after its
+        // dL/d(raw output) is final, so forks are shared: layers wait in `pending` and ONE fork serves `fork_every` of them
+        // (UNET_FORK_EVERY, 1 = a fork per layer as in round 2).
+        static const int fork_every = getenv("UNET_FORK_EVERY") ? std::max(1, atoi(getenv("UNET_FORK_EVERY"))) : 3;
+        std::vector<int> pending;
+        auto issue_pending = [&]() {
+            if (pending.empty()) return;
+            fork();
+            for (int h : pending) do_wgrad(h);
+            pending.clear();
+        };
         for (int i = (int)g.ops.size() - 1; i >= op_lo; --i) {
             const Op& op = g.ops[i];
             const bool dry = i >= op_hi;
@@ -671,12 +706,15 @@ struct Exec {
                         const int64_t vox = (int64_t)cg.Do * cg.Ho * cg.Wo;
                         if (!deep_seen && vox <= hold_below && !held.empty()) {     // the small levels begin: the held launches run beside them
                             deep_seen = true;
-                            fork();
-                            for (int h : held) do_wgrad(h);
+                            pending.insert(pending.begin(), held.begin(), held.end());
                             held.clear();
+                            pending.push_back(i);
+                            issue_pending();
+                        } else if (!deep_seen && sb != s && vox >= hold_from) held.push_back(i);
+                        else {
+                            pending.push_back(i);
+                            if ((int)pending.size() >= fork_every || sb == s) issue_pending();
                         }
-                        if (!deep_seen && sb != s && vox >= hold_from) held.push_back(i);
-                        else { fork(); do_wgrad(i); }
                     }
                     if (op.kind == OP_CONV) {
                         ProfScope pd(i, UNET_PROF_DGRAD, s);
@@ -694,9 +732,6 @@ struct Exec {
                             const bool can = op.nsrc == 1 && Ts.norm >= 0 && p.n_consumers[ts] == 1 && p.dtype == UNET_DTYPE_BF16;
                             const int rows = launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s, can ? &bn : nullptr);
                             if (rows > 0) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending[ws] = {ts, rows}; }
-                            static const bool dbg = getenv("UNET_DEBUG_BNSTATS") != nullptr;
-                            if (dbg) fprintf(stderr, "dgrad of op %d (%s): source tensor %d consumers %d norm %d -> bn rows %d\n", i, op.name.c_str(), ts,
-                                             p.n_consumers[ts], Ts.norm, rows);
                         }
                         else if (!dry && any && p.impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(p.dtype, cg, dg, op.nsrc))
                             launch_conv_f32_mfma_dgrad(cg, (const float*)gptr(t), wd, dg, op.nsrc, s);
@@ -736,7 +771,9 @@ struct Exec {
                 default: break;
             }
         }
-        if (!held.empty()) { fork(); for (int h : held) do_wgrad(h); held.clear(); }
+        pending.insert(pending.begin(), held.begin(), held.end());
+        held.clear();
+        issue_pending();
         flush_wz(sb);
         if (sb != s) {   // join: whatever the caller enqueues next (optimizer step, next forward) sees every gradient
             HIP_OK(hipEventRecord(p.ev_join, sb));
@@ -822,8 +859,12 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
             int pr_least = 0, pr_greatest = 0;   // the side stream yields to the caller's (critical-path) stream
             (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
             HIP_OK(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, pr_least));
-            HIP_OK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-            HIP_OK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+            // the plan's events only order its two streams on ONE device: no host ever waits on them, so the system-scope fence a
+            // default event performs when it is recorded (cache write-back for host visibility) is not needed (UNET_EVENT_SYSFENCE=1 keeps it)
+            const unsigned evf = hipEventDisableTiming | ((getenv("UNET_EVENT_SYSFENCE") && getenv("UNET_EVENT_SYSFENCE")[0] == '1') ? 0u : hipEventDisableSystemFence);
+            HIP_OK(hipEventCreateWithFlags(&p->ev_fork, evf));
+            HIP_OK(hipEventCreateWithFlags(&p->ev_join, evf));
+            HIP_OK(hipEventCreateWithFlags(&p->ev_pack, evf));
             HIP_OK(hipMalloc((void**)&p->segs_dev, segs.size() * sizeof(SgdSeg)));
             HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
             if (!p->wz_jobs.empty()) {
@@ -1102,7 +1143,15 @@ int unet_loss(const unet_plan* p, const float* const* outs, const int64_t* targe
 int unet_forward_loss(const unet_plan* p, const float* const* params, float* const* buffers, const float* x, float* const* outs,
                       const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
                       void* loss_scratch, void* workspace, void* stream) {
+    return unet_forward_loss_mode(p, params, buffers, x, outs, target, cost_mask, collapse_before, grad_outs, losses_out, loss_scratch, workspace, 1,
+                                  stream);
+}
+
+int unet_forward_loss_mode(const unet_plan* p, const float* const* params, float* const* buffers, const float* x, float* const* outs,
+                           const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
+                           void* loss_scratch, void* workspace, int mode, void* stream) {
     try {
+        if ((mode & 1) != 1) throw std::runtime_error("unet_forward_loss_mode: mode must be 1 (train), optionally | UNET_MODE_PACKS_CURRENT");
         if (!p || !params || !x || !workspace || !outs) throw std::runtime_error("unet_forward_loss: null argument");
         if (!p->g.buffers.empty() && !buffers) throw std::runtime_error("unet_forward_loss: architecture has bnorm layers but buffers is null");
         LossRun lr(p, outs, target, cost_mask, collapse_before, grad_outs, losses_out, loss_scratch);
@@ -1112,7 +1161,7 @@ int unet_forward_loss(const unet_plan* p, const float* const* params, float* con
         const bool side = p->side && !no_side && !g_prof;
         Exec ex(*p, workspace, stream);
         if (!side) {
-            ex.forward(params, buffers, x, outs, 1);
+            ex.forward(params, buffers, x, outs, mode);
             lr.prepare(s);
             for (size_t k = 0; k < lr.levels(); ++k) { lr.level_partial(k, 0, s); lr.level_finish(k, 0, s); }
             check_launch();
@@ -1120,15 +1169,22 @@ int unet_forward_loss(const unet_plan* p, const float* const* params, float* con
         }
         hipStream_t sd = p->side;
         bool prepared = false;
+        // ONE fork for all coarse levels, taken when the last of them (level 1) has its head: an event record costs the caller's stream
+        // ~6 us, the coarse levels' loss kernels ~0.1 ms in all, and the full-resolution decoder level that follows (~0.25 ms) covers them
+        // (UNET_LOSS_FORK_PER_LEVEL: a fork per level as in round 2)
+        static const bool per_level = getenv("UNET_LOSS_FORK_PER_LEVEL") != nullptr;
         std::function<void(int)> on_head = [&](int level) {
             if (level < 1 || (size_t)level >= lr.levels()) return;
-            HIP_OK(hipEventRecord(p->ev_fork, s));             // results[level] is final on the caller's stream here (and so is `target`)
+            if (!per_level && level != 1) return;
+            HIP_OK(hipEventRecord(p->ev_fork, s));             // results[level..] are final on the caller's stream here (and so is `target`)
             HIP_OK(hipStreamWaitEvent(sd, p->ev_fork, 0));
             if (!prepared) { lr.prepare(sd); prepared = true; }   // not at entry: the forward's filter pack goes first on the side stream
-            lr.level_partial((size_t)level, 1, sd);
-            lr.level_finish((size_t)level, 1, sd);
+            for (size_t k = per_level ? (size_t)level : lr.levels() - 1; k >= (size_t)level; --k) {   // coarsest first: the order of the totals' sum
+                lr.level_partial(k, 1, sd);
+                lr.level_finish(k, 1, sd);
+            }
         };
-        ex.forward(params, buffers, x, outs, 1, &on_head);
+        ex.forward(params, buffers, x, outs, mode, &on_head);
         if (!prepared) {   // a single-level architecture: nothing went to the side stream
             HIP_OK(hipEventRecord(p->ev_fork, s));
             HIP_OK(hipStreamWaitEvent(sd, p->ev_fork, 0));

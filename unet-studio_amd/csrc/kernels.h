@@ -136,7 +136,9 @@ void launch_sgd(float* p, float* g, float* m, int64_t n, const SgdSeg* segs_dev,
 struct PackJob { int64_t src_off, dst_off, total, blk0; int Ci, Co, CK, T, mode, A, B, pad; };
 int mfma_conv_pack_jobs(const ConvGeom& g, bool want_dgrad, PackJob* out2);
 int mfma_convt_pack_jobs(const ConvGeom& g, PackJob* out2);
-void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s);
+// one launch serves the pack units [blk_base, blk_base + nblocks) of the table (njobs = the whole table)
+void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s,
+                              int64_t blk_base = 0);
 bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_conv_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
@@ -171,6 +173,9 @@ size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
 // defer_reduce: only the slab ([rows][n] + [rows][Cout] bias partials at `scratch`) is written; rows = *_wgrad_splits(g)
 int mfma_conv_wgrad_splits(const ConvGeom& g);
 int mfma_convt_wgrad_splits(const ConvGeom& g);
+// small volumes: the launch ADDS its result into dw / db itself (output-stationary blocks; no slab, defer_reduce is ignored)
+bool mfma_conv_wgrad_direct(const ConvGeom& g);
+bool mfma_convt_wgrad_direct(const ConvGeom& g);
 int conv_first_wgrad_splits(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s, bool defer_reduce = false);

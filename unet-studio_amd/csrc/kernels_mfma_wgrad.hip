@@ -30,6 +30,10 @@ struct MfmaWgradArgs {
     float* slab;       // [nsplit][Cb][Ca][T]
     float* bias_slab;  // [nsplit][Cb] or nullptr: per-channel sums of the RAW tile-side tensor
     int tiles_x, tiles_y, tiles_z;
+    // direct != 0 (one block per (ca, cb) pair walks ALL tiles: gridDim.x == 1): `slab` IS the gradient tensor (same layout) and
+    // `bias_slab` the bias gradient; the block ADDS its result to them (.grad accumulates) -- no slab, no reduce pass.  Every
+    // gradient element belongs to exactly one block and is summed in a fixed order, so the result stays bit-reproducible.
+    int direct;
 };
 
 __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
@@ -272,9 +276,27 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
             }
         __syncthreads();
         float* base = a.slab + (size_t)blockIdx.x * T * g.Cin * g.Cout + ((size_t)coB * 16 * g.Cin + (size_t)ciB * 16) * T;
+        if (a.direct) {
+            // the gradient itself: read-modify-write.  A flat parameter buffer only guarantees 4-B alignment of a tensor (6-float head
+            // biases may sit in front of it): 16-B accesses when the tensor happens to be aligned, scalars otherwise.
+            if ((reinterpret_cast<uintptr_t>(base) & 15) == 0) {
+                for (int q = tid; q < 16 * ROW4; q += 256) {
+                    const int row = q / ROW4, c4 = q % ROW4;
+                    f32x4* d = (f32x4*)(base + (size_t)row * g.Cin * T + c4 * 4);
+                    const f32x4 o = *d, v = *(const f32x4*)(stg + row * RP + c4 * 4);
+                    *d = f32x4{o[0] + v[0], o[1] + v[1], o[2] + v[2], o[3] + v[3]};
+                }
+            } else {
+                for (int q = tid; q < 16 * 16 * T; q += 256) {
+                    const int row = q / (16 * T), c = q % (16 * T);
+                    base[(size_t)row * g.Cin * T + c] += stg[row * RP + c];
+                }
+            }
+        } else {
         for (int q = tid; q < 16 * ROW4; q += 256) {
             const int row = q / ROW4, c4 = q % ROW4;
             *(f32x4*)(base + (size_t)row * g.Cin * T + c4 * 4) = *(const f32x4*)(stg + row * RP + c4 * 4);
+        }
         }
     }
     if constexpr (!TS) {
@@ -343,7 +365,8 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
 #pragma unroll
             for (int w = 0; w < 4; ++w) sacc += bred[(w * GB + u) * 8 + e];
             int c = (coB + (u >> 1)) * 16 + (u & 1) * 8 + e;
-            a.bias_slab[(size_t)blockIdx.x * g.Cout + c] = sacc;
+            if (a.direct) a.bias_slab[c] += sacc;     // the bias gradient itself (one block per channel: ciB == 0)
+            else a.bias_slab[(size_t)blockIdx.x * g.Cout + c] = sacc;
         }
     }
 }
@@ -649,10 +672,27 @@ bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src
 }
 
 // kind 0: conv stride 1, 1: conv stride 2, 2: conv_trans.  Ca/Cb and the tile-side grid width decide the configuration.
-struct WgradCfg { int bz, by, bx, pi, pj, nsplit, gy; };
+struct WgradCfg { int bz, by, bx, pi, pj, nsplit, gy, direct; };
+// Small volumes (tile side 4^3 or 8^3 voxels: the 8^3 / 4^3 levels of the default architecture, K = 64..512 voxels, gradients of
+// 2..14 MB): output-stationary.  One block per (ca, cb) pair owns the pair's T tap tiles for the WHOLE volume (4 waves split the
+// taps), walks the volume's tiles and adds its result straight into the gradient: >= 128 blocks, no slab write, no reduce read.
+// (Round 2 ran these as 64..128 blocks of 2x2 pairs with one LDS read pair in flight per MFMA, each writing a 110-KB slab tile:
+// 20..43 us per layer for < 0.3 % of the step's FLOPs.)
+static bool wgrad_direct_cfg(int kind, int bD, int bH, int bW, WgradCfg& c) {
+    static const bool off = getenv("UNET_NO_WGRAD_DIRECT") != nullptr;
+    if (off || bD != bH || bH != bW) return false;
+    if (bW == 4) { c.bz = 4; c.by = 4; c.bx = 4; }
+    else if (bW == 8 && kind == 0) { c.bz = 8; c.by = 8; c.bx = 8; }      // stride 1: the 10^3 halo of a 16-channel tile is 32 KB
+    else if (bW == 8) { c.bz = 2; c.by = 8; c.bx = 8; }                   // stride 2 / conv_trans: halo planes of 17^2 / 16^2 voxels, 4 tiles along z
+    else return false;
+    c.pi = c.pj = 1; c.nsplit = 1; c.direct = 1;
+    return true;
+}
 static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
     WgradCfg c;
+    c.direct = 0;
     int cat = Ca / 16, cbt = Cb / 16;
+    if (wgrad_direct_cfg(kind, bD, bH, bW, c)) { c.gy = cat * cbt; return c; }
     if (kind == 0) {
         c.pi = cat % 2 == 0 ? 2 : 1; c.pj = cbt % 2 == 0 ? 2 : 1;
         // One (ca, cb) pair per block with the 4 waves splitting K is what lets the next tile's loads ride in registers
@@ -699,6 +739,7 @@ static void launch_wgrad_cfg(const MfmaWgradArgs& a0, const WgradCfg& c, hipStre
     static std::atomic<uint64_t> attr_done{0};
     set_max_lds_once(attr_done, (const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, (int)lds);
     dim3 grid((unsigned)c.nsplit, (unsigned)c.gy);
+    a.direct = c.direct;
     k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ><<<grid, 256, lds, s>>>(a);
 }
 template <int S, int KD, int PAD, int BZ, int BY, int BX>
@@ -721,6 +762,12 @@ int mfma_conv_wgrad_splits(const ConvGeom& g) {
     return wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo).nsplit;
 }
 int mfma_convt_wgrad_splits(const ConvGeom& g) { return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).nsplit; }
+// the launch adds into the gradient itself (no slab, nothing for a reduce pass to do)
+bool mfma_conv_wgrad_direct(const ConvGeom& g) {
+    if (mfma_wgrad_z_splits(g)) return false;
+    return wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo).direct != 0;
+}
+bool mfma_convt_wgrad_direct(const ConvGeom& g) { return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).direct != 0; }
 // defer_reduce: leave the slab for the caller's batched reduce (launch_wgrad_reduce_batched) instead of summing it here
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s, bool defer_reduce) {
@@ -738,6 +785,14 @@ void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, con
     a.slab = (float*)scratch;
     a.bias_slab = db ? a.slab + (size_t)c.nsplit * 27 * g.Cin * g.Cout : nullptr;
     a.tiles_x = a.tiles_y = a.tiles_z = 0;
+    if (c.direct) {   // the block adds into dw / db themselves
+        a.slab = dw; a.bias_slab = db;
+        if (g.stride == 1 && c.bx == 4) launch_wgrad_cfg<1, 3, 1, 4, 4, 4, 1, 1>(a, c, s);
+        else if (g.stride == 1) launch_wgrad_cfg<1, 3, 1, 8, 8, 8, 1, 1>(a, c, s);
+        else if (c.bx == 4) launch_wgrad_cfg<2, 3, 1, 4, 4, 4, 1, 1>(a, c, s);
+        else launch_wgrad_cfg<2, 3, 1, 2, 8, 8, 1, 1>(a, c, s);
+        return;
+    }
     if (g.stride == 1) {
         if (g.Wo >= 12) launch_wgrad_p<1, 3, 1, 2, 8, 16>(a, c, s);
         else if (g.Wo > 4) launch_wgrad_p<1, 3, 1, 4, 8, 8>(a, c, s);
@@ -761,6 +816,12 @@ void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* 
     a.bsrc = src[0];
     a.slab = (float*)scratch; a.bias_slab = nullptr;
     a.tiles_x = a.tiles_y = a.tiles_z = 0;
+    if (c.direct) {
+        a.slab = dw;
+        if (c.bx == 4) launch_wgrad_cfg<2, 2, 0, 4, 4, 4, 1, 1>(a, c, s);
+        else launch_wgrad_cfg<2, 2, 0, 2, 8, 8, 1, 1>(a, c, s);
+        return;
+    }
     if (g.W >= 12) launch_wgrad_p<2, 2, 0, 2, 4, 16>(a, c, s);
     else if (g.W > 4) launch_wgrad_p<2, 2, 0, 2, 8, 8>(a, c, s);
     else launch_wgrad_p<2, 2, 0, 4, 8, 4>(a, c, s);

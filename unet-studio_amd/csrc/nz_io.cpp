@@ -36,35 +36,52 @@ bool put(gzFile f, const std::string& name, int p, int text, int rows, int cols,
 }
 bool put_text(gzFile f, const std::string& name, const std::string& s) { return put(f, name, 5, 1, 1, (int)s.size(), s.data()); }
 
+struct GzFile {   // closes on every path out of read_all, exceptions included
+    gzFile f;
+    explicit GzFile(gzFile g) : f(g) {}
+    ~GzFile() { if (f) gzclose(f); }
+    GzFile(const GzFile&) = delete;
+    GzFile& operator=(const GzFile&) = delete;
+};
+// the largest record a network file can hold: the whole default architecture is 60 MB; 16 GiB leaves room for any DSL-legal network
+// and still rejects a corrupt or crafted header before anything is allocated for it
+const uint64_t kMaxRecordBytes = 1ull << 34;
+
 bool read_all(const char* file_name, std::map<std::string, Rec>& recs, std::string& err)
 {
-    gzFile f = gzopen(file_name, "rb");
+    GzFile gz(gzopen(file_name, "rb"));
+    gzFile f = gz.f;
     if (!f) { err = std::string("cannot open ") + file_name; return false; }
     for (;;) {
         int32_t h[5];
         int got = gzread(f, h, sizeof(h));
         if (got == 0) break;
-        if (got != (int)sizeof(h)) { err = "truncated record header"; gzclose(f); return false; }
+        if (got != (int)sizeof(h)) { err = "truncated record header"; return false; }
         int typ = h[0], m = typ / 1000, o = (typ % 1000) / 100, p = (typ % 100) / 10, t = typ % 10;
-        if (m != 0 || o != 0 || p < 0 || p > 5 || t > 1 || h[1] < 0 || h[2] < 0 || h[4] < 1 || h[4] > 4096 || (h[3] != 0 && h[3] != 1)) {
-            err = "not a little-endian Level-4 MAT record"; gzclose(f); return false;
+        if (typ < 0 || m != 0 || o != 0 || p < 0 || p > 5 || t > 1 || h[1] < 0 || h[2] < 0 || h[4] < 1 || h[4] > 4096 || (h[3] != 0 && h[3] != 1)) {
+            err = "not a little-endian Level-4 MAT record"; return false;
         }
         std::string name((size_t)h[4], '\0');
-        if (gzread(f, &name[0], (unsigned)h[4]) != h[4]) { err = "truncated record name"; gzclose(f); return false; }
+        if (gzread(f, &name[0], (unsigned)h[4]) != h[4]) { err = "truncated record name"; return false; }
         name = name.c_str();
         Rec r;
         r.p = p; r.text = t; r.rows = h[1]; r.cols = h[2];
-        size_t n = (size_t)h[1] * h[2] * kElem[p] * (h[3] ? 2 : 1);
-        r.data.resize(n);
+        // rows * cols * element size: both factors are < 2^31, so the product of the first two fits 64 bits; the cap bounds the rest
+        const uint64_t cells = (uint64_t)h[1] * (uint64_t)h[2];
+        const uint64_t per = (uint64_t)kElem[p] * (h[3] ? 2 : 1);
+        if (cells > kMaxRecordBytes / per) { err = "record " + name + " declares an implausible size"; return false; }
+        const size_t n = (size_t)(cells * per);
+        // read in pieces and grow as the bytes arrive: a header that promises more than the stream holds fails on the short read
+        // without the promised amount ever having been allocated
         size_t off = 0;
         while (off < n) {
-            unsigned c = n - off > (1u << 30) ? (1u << 30) : (unsigned)(n - off);
-            if (gzread(f, r.data.data() + off, c) != (int)c) { err = "record " + name + " is truncated"; gzclose(f); return false; }
-            off += c;
+            const size_t piece = n - off > ((size_t)64 << 20) ? ((size_t)64 << 20) : n - off;
+            r.data.resize(off + piece);
+            if (gzread(f, r.data.data() + off, (unsigned)piece) != (int)piece) { err = "record " + name + " is truncated"; return false; }
+            off += piece;
         }
         recs[name] = std::move(r);
     }
-    gzclose(f);
     return true;
 }
 
@@ -97,6 +114,8 @@ bool save_to_file(UNet3d& model, const char* file_name)
     int32_t ch[2] = {model->in_count, model->out_count};
     ok = ok && put(f, "channels", 2, 0, 1, 2, ch);
     ok = ok && put_text(f, "architecture", model->architecture);
+    // (the reference hands TIPL a uint32 shape, main.cpp:214; Level 4 has no 32-bit unsigned type code, and which code TIPL picks for
+    // it is not visible here: written as int32 -- identical bytes for every real volume size -- and read back through elem() whatever the code)
     int32_t dim[3] = {(int32_t)model->dim[0], (int32_t)model->dim[1], (int32_t)model->dim[2]};
     ok = ok && put(f, "dimension", 2, 0, 1, 3, dim);
     float vs[3] = {model->voxel_size[0], model->voxel_size[1], model->voxel_size[2]};
@@ -116,7 +135,20 @@ bool save_to_file(UNet3d& model, const char* file_name)
     return ok;
 }
 
+static bool load_from_file_impl(UNet3d& model, const char* file_name);
+
+// contract of main.cpp:157-206: false + error_msg, never an exception (a corrupt file must not take the caller down with bad_alloc)
 bool load_from_file(UNet3d& model, const char* file_name)
+{
+    try { return load_from_file_impl(model, file_name); }
+    catch (const std::exception& e) {
+        if (!model.is_empty()) model->error_msg = e.what();
+        std::cerr << e.what() << std::endl;
+        return false;
+    }
+}
+
+static bool load_from_file_impl(UNet3d& model, const char* file_name)
 {
     std::map<std::string, Rec> recs;
     std::string err;

@@ -165,7 +165,20 @@ void UNet3dImpl::ensure_flat(void)
     }
     if (!trigger_.defined() || trigger_.device() != dev) {
         trigger_ = torch::zeros({1}, torch::TensorOptions().device(dev).requires_grad(true));
-        if (momentum_.defined()) momentum_ = momentum_.to(dev);
+        if (momentum_.defined()) {
+            // the optimizer state's momentum_buffer tensors alias momentum_ (bind_optimizer_state): drop the aliases before the
+            // buffer they point into is replaced; the next bind re-aliases the moved buffer without copying from freed memory
+            if (optimizer) {
+                const char* lo = (const char*)momentum_.data_ptr();
+                const char* hi = lo + momentum_.numel() * sizeof(float);
+                for (auto& kv : optimizer->state()) {
+                    auto& ps = static_cast<torch::optim::SGDParamState&>(*kv.second);
+                    const char* q = ps.momentum_buffer().defined() ? (const char*)ps.momentum_buffer().data_ptr() : nullptr;
+                    if (q && q >= lo && q < hi) ps.momentum_buffer(torch::Tensor());
+                }
+            }
+            momentum_ = momentum_.to(dev);
+        }
         scratch_ = torch::Tensor();
         std::scoped_lock<std::mutex> lock(plans_mutex_);
         for (auto& kv : plans_) unet_plan_destroy(kv.second);   // plans are bound to a device
@@ -219,11 +232,12 @@ size_t UNet3dImpl::pooled_workspaces(void) const { return ws_pool_ ? ws_pool_->c
 torch::Tensor UNet3dImpl::workspace_for(unet_plan* plan)
 {
     auto dev = device();
-    if (!ws_pool_) {
+    std::shared_ptr<WorkspacePool> pool;
+    {   // created and read under the lock (no unsynchronised first read of the shared_ptr)
         std::scoped_lock<std::mutex> lock(plans_mutex_);
         if (!ws_pool_) ws_pool_ = std::make_shared<WorkspacePool>();
+        pool = ws_pool_;
     }
-    auto pool = ws_pool_;
     WorkspacePool::Entry e;
     {
         std::scoped_lock<std::mutex> lock(pool->m);
@@ -231,8 +245,12 @@ torch::Tensor UNet3dImpl::workspace_for(unet_plan* plan)
         if (!v.empty()) { e = v.back(); v.pop_back(); }
     }
     c10::DeviceGuard guard(dev);
+    // the stream this lease's kernels are enqueued on: the forward runs on it now, and autograd runs the node's backward on the
+    // forward's stream whatever thread executes it -- so this, not "the current stream of whichever thread drops the last
+    // reference", is where the buffer's last use is ordered
+    void* const lease_stream = stream_of(dev);
     if (e.buf.defined()) {
-        if (e.ev) (void)hipStreamWaitEvent((hipStream_t)stream_of(dev), e.ev, 0);   // the previous user's kernels come first
+        if (e.ev) (void)hipStreamWaitEvent((hipStream_t)lease_stream, e.ev, 0);   // the previous user's kernels come first
     } else {
         size_t bytes = 0;
         unet_plan_workspace_bytes(plan, &bytes);
@@ -242,11 +260,11 @@ torch::Tensor UNet3dImpl::workspace_for(unet_plan* plan)
     // the lease aliases the pooled buffer; its deleter (run when the last reference dies: end of a no-grad forward, or the
     // autograd node's saved data after backward / when the outputs are dropped) hands the buffer back
     std::weak_ptr<WorkspacePool> wp = pool;
-    auto back = [wp, e, plan, dev](void*) mutable {
+    auto back = [wp, e, plan, dev, lease_stream](void*) mutable {
         auto p = wp.lock();
         if (e.ev && dev.is_cuda()) {
             c10::DeviceGuard g(dev);
-            (void)hipEventRecord(e.ev, (hipStream_t)stream_of(dev));
+            (void)hipEventRecord(e.ev, (hipStream_t)lease_stream);
         }
         if (p) {
             std::scoped_lock<std::mutex> lock(p->m);
@@ -455,6 +473,18 @@ void UNet3dImpl::broadcast_parameters(int root)
     check(unet_comm_join(comm_, st));
 }
 
+// BatchNorm running statistics: copy_from overwrites every replica's buffers with the root's each step (unet.cpp:207-215,
+// train.cpp:573-579), so only the root's statistics exist in the reference; the same here (validation / a checkpoint agree on any rank)
+void UNet3dImpl::broadcast_buffers(int root)
+{
+    if (!comm_) throw std::runtime_error("broadcast_buffers: no communicator attached");
+    if (buffers_.empty()) return;
+    ensure_flat();
+    void* st = stream_of(flat_params.device());
+    for (auto& b : buffers_) check(unet_comm_broadcast(comm_, b.data_ptr<float>(), b.numel(), root, st));
+    check(unet_comm_join(comm_, st));
+}
+
 void UNet3dImpl::allreduce_gradients(void)
 {
     if (!comm_) throw std::runtime_error("allreduce_gradients: no communicator attached");
@@ -463,6 +493,8 @@ void UNet3dImpl::allreduce_gradients(void)
     void* st = stream_of(flat_grads.device());
     const int64_t hi = reduced_from_ >= 0 ? reduced_from_ : flat_grads.numel();   // buckets above were started by the overlapped backward
     check(unet_allreduce_grads(comm_, flat_grads.data_ptr<float>(), 0, hi, st));
+    // the forwards of this step have updated each rank's own running statistics: they follow rank 0, every step, like the Python trainer
+    for (auto& b : buffers_) check(unet_comm_broadcast(comm_, b.data_ptr<float>(), b.numel(), 0, st));
     check(unet_comm_join(comm_, st));
     reduced_from_ = -1;
 }
@@ -515,11 +547,65 @@ torch::Tensor UNet3dImpl::loss_and_backward_overlapped(torch::Tensor input, torc
     return losses;
 }
 
+// ---- train.cpp:787 (torch::save(*optimizer, model_path + ".opt")) and :945-957 (torch::load on resume) ------------------------------
+// The fused update (sgd_step) keeps its momentum in ONE flat buffer.  So that the optimizer object the callers hold stays the
+// resume path, the per-parameter `momentum_buffer` tensors of torch::optim::SGD's state are made aliases of that buffer: whichever
+// of optimizer->step() (train.cpp:765) and sgd_step() runs, both read and write the same momentum, and torch::save / torch::load of
+// *optimizer carry it.  After a torch::load the state holds fresh tensors: bind_optimizer_state() copies them in and re-aliases.
+void UNet3dImpl::bind_optimizer_state(void)
+{
+    ensure_flat();
+    if (!momentum_.defined() || momentum_.device() != flat_params.device() || momentum_.numel() != flat_params.numel())
+        momentum_ = momentum_.defined() && momentum_.numel() == flat_params.numel() ? momentum_.to(flat_params.device()) : torch::zeros_like(flat_params);
+    if (!optimizer) return;
+    torch::NoGradGuard ng;
+    auto& st = optimizer->state();
+    auto opts = torch::TensorOptions().dtype(torch::kFloat32).device(momentum_.device());
+    int64_t off = 0;
+    for (auto& p : params_) {
+        float* slot = momentum_.data_ptr<float>() + off;
+        off += p.numel();
+        void* key = p.unsafeGetTensorImpl();
+        auto it = st.find(key);
+        if (it == st.end()) {
+            auto ps = std::make_unique<torch::optim::SGDParamState>();
+            ps->momentum_buffer(torch::from_blob(slot, p.sizes(), opts));
+            st[key] = std::move(ps);
+            continue;
+        }
+        auto& ps = static_cast<torch::optim::SGDParamState&>(*it->second);
+        if (ps.momentum_buffer().defined() && ps.momentum_buffer().data_ptr() == (void*)slot) continue;
+        auto alias = torch::from_blob(slot, p.sizes(), opts);
+        if (ps.momentum_buffer().defined()) alias.copy_(ps.momentum_buffer().reshape(p.sizes()));
+        ps.momentum_buffer(alias);
+    }
+}
+
+bool UNet3dImpl::save_optimizer(const std::string& file_name)
+{
+    try {
+        if (!optimizer) throw std::runtime_error("save_optimizer: no optimizer (create_optimizer first)");
+        bind_optimizer_state();
+        torch::save(*optimizer, file_name);
+        return true;
+    } catch (const std::exception& e) { error_msg = std::string("cannot save optimizer: ") + e.what(); return false; }
+}
+
+bool UNet3dImpl::load_optimizer(const std::string& file_name)
+{
+    try {
+        if (!optimizer) throw std::runtime_error("load_optimizer: no optimizer (create_optimizer first)");
+        torch::load(*optimizer, file_name);
+        bind_optimizer_state();
+        return true;
+    } catch (const std::exception& e) { error_msg = std::string("cannot load optimizer: ") + e.what(); return false; }   // train.cpp:953-955
+}
+
 void UNet3dImpl::sgd_step(float lr, float grad_scale, float clip_norm)
 {
     ensure_flat();
     rebind_grads();
-    if (!momentum_.defined()) momentum_ = torch::zeros_like(flat_params);
+    bind_optimizer_state();
     if (!scratch_.defined()) scratch_ = torch::empty({65536 + 16}, torch::TensorOptions().dtype(torch::kUInt8).device(flat_params.device()));
     if (plans_.empty()) throw std::runtime_error("sgd_step before any forward");
     check(unet_sgd_step(plans_.begin()->second, flat_params.data_ptr<float>(), flat_grads.data_ptr<float>(), momentum_.data_ptr<float>(), lr,

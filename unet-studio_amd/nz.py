@@ -113,9 +113,13 @@ def load_from_file(file_name, make_model):
     if "channels" not in recs or "architecture" not in recs:
         raise NzError("invalid format")
     ch = np.asarray(recs["channels"][0]).reshape(-1)
+    if ch.size < 2:
+        raise NzError("invalid format")
     arch = _text(recs["architecture"])
     model = make_model(int(ch[0]), int(ch[1]), arch)
     if "dimension" not in recs or "voxel_size" not in recs:
+        raise NzError("invalid format")
+    if np.asarray(recs["dimension"][0]).size < 3 or np.asarray(recs["voxel_size"][0]).size < 3:
         raise NzError("invalid format")
     model.dim = tuple(int(v) for v in np.asarray(recs["dimension"][0]).reshape(-1)[:3])
     model.voxel_size = tuple(float(v) for v in np.asarray(recs["voxel_size"][0]).reshape(-1)[:3])

@@ -55,6 +55,8 @@ class Trainer:
             self.rank, self.world_size = comm.rank, comm.world
         # world_size > 1: start the all-reduce of every finished gradient bucket under the rest of the backward
         self.overlap = os.environ.get("UNET_NO_OVERLAP") is None
+        # micro-steps 2.. of a step skip the filter repack (UNET_MODE_PACKS_CURRENT); models without the keyword (test stand-ins) do not
+        self.packs_reuse = os.environ.get("UNET_NO_PACK_REUSE") is None and hasattr(model, "_run_forward_loss")
         self.cur_epoch = 0
         model.train()
         if model.optimizer is None:
@@ -90,11 +92,13 @@ class Trainer:
 
         for k, b in enumerate(mine):
             x, t = self.source(cur_data_index + b)
+            # the parameters only change at the end of the step (train.cpp:765): this rank's micro-steps 2.. reuse the filter packs of its first
+            cur = self.packs_reuse and k > 0
             if overlap and k == len(mine) - 1:
                 # gradients accumulate over this rank's micro-steps: only the last backward can hand finished buckets to RCCL
-                losses = m.forward_backward_bucketed(x, t, reduce_bucket, p.cost_ce, p.cost_dice, p.cost_mse)
+                losses = m.forward_backward_bucketed(x, t, reduce_bucket, p.cost_ce, p.cost_dice, p.cost_mse, packs_current=cur)
             else:
-                losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse)
+                losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse, packs_current=cur)
             self._stats += losses
             count += 1
         if self.comm is not None:

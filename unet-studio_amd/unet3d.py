@@ -52,7 +52,10 @@ class SGD:
         return {"momentum_buffer": self.momentum_buffer.clone(), "lr": self.param_groups[0]["lr"]}
 
     def load_state_dict(self, sd):
-        self.momentum_buffer.copy_(sd["momentum_buffer"])
+        if sd["momentum_buffer"].numel() != self.momentum_buffer.numel():
+            raise E.UNetError("optimizer state does not belong to this architecture: %d momentum elements, %d parameters"
+                              % (sd["momentum_buffer"].numel(), self.momentum_buffer.numel()))
+        self.momentum_buffer.copy_(sd["momentum_buffer"].to(self.momentum_buffer.device))
         for g in self.param_groups:
             g["lr"] = sd["lr"]
 
@@ -203,6 +206,30 @@ class UNet3d:
         self.optimizer = SGD(self, learning_rate)
         return self.optimizer
 
+    def save_optimizer(self, file_name):
+        """torch::save(*(model->optimizer), model_path + ".opt") -- train.cpp:787: the momentum of the fused update (and the learning
+        rate), so that a run resumed from <model>.nz + <model>.nz.opt continues exactly.  Returns False + error_msg on failure."""
+        try:
+            if self.optimizer is None:
+                raise E.UNetError("save_optimizer: no optimizer (create_optimizer first)")
+            sd = self.optimizer.state_dict()
+            torch.save({"momentum_buffer": sd["momentum_buffer"].cpu(), "lr": sd["lr"]}, file_name)
+            return True
+        except (OSError, RuntimeError) as e:
+            self.error_msg = "cannot save optimizer: %s" % e
+            return False
+
+    def load_optimizer(self, file_name):
+        """torch::load(*(model->optimizer), model_path + ".opt") -- train.cpp:945-957 ("cannot load optimizer: ..." on failure)."""
+        try:
+            if self.optimizer is None:
+                raise E.UNetError("load_optimizer: no optimizer (create_optimizer first)")
+            self.optimizer.load_state_dict(torch.load(file_name, map_location="cpu"))
+            return True
+        except (OSError, RuntimeError, KeyError) as e:
+            self.error_msg = "cannot load optimizer: %s" % e
+            return False
+
     def prepare_for_inference(self, device=None):
         """unet.cpp:7-22: eval() and running_mean 0 / running_var 1 / num_batches_tracked 0 on every BatchNorm3d."""
         self.eval()
@@ -259,7 +286,7 @@ class UNet3d:
         pp, bp = self._pp, self._bp
         op = E.ptr_array([o.data_ptr() if o is not None else None for o in outs])
         E.check(E.lib.unet_forward(plan.handle, pp, bp, x.data_ptr(), op, ws.data_ptr(), mode, _stream_ptr(self._device)))
-        if mode == 1 and self._buffers:
+        if (mode & 1) and self._buffers:
             self.num_batches_tracked += 1
         return outs
 
@@ -275,14 +302,14 @@ class UNet3d:
         E.check(E.lib.unet_backward_part(plan.handle, pp, go, gp, None, ws.data_ptr(), op_hi, op_lo, _stream_ptr(self._device)))
 
     def forward_backward_bucketed(self, x, target, on_bucket, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0,
-                                  max_buckets=3):
+                                  max_buckets=3, packs_current=False):
         """forward_backward with the backward issued in buckets: on_bucket(elem_lo, elem_hi) is called after each part, when the
         gradients flat_grads[elem_lo:elem_hi] are final on the current stream (the data-parallel trainer starts their all-reduce
         there, so that it runs under the rest of the backward)."""
         x = self._check_input(x)
         plan = self.plan_for(x.shape[2:])
         ws = self._workspace(plan)
-        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before)
+        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current)
         op_hi, elem_hi = 1 << 30, int(self.flat_grads.numel())
         for op_lo, elem_lo in plan.backward_buckets(max_buckets):
             self._run_backward_part(plan, ws, gouts, op_hi, op_lo)
@@ -312,14 +339,15 @@ class UNet3d:
     __call__ = forward
 
     # ---- fused train micro-step (train.cpp:615-706 for one sample) ----
-    def forward_backward(self, x, target, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0):
+    def forward_backward(self, x, target, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0, packs_current=False):
         """forward + calc_losses over all deep-supervision levels + backward, all in the engine.
         target: int64 {1,D,H,W}.  Returns a device tensor {total, ce0, dice0, mse0}; gradients are ACCUMULATED
-        into grads()."""
+        into grads().  packs_current: the caller asserts that a training forward has run on this thread's workspace since the
+        parameters last changed (micro-steps 2.. of one optimizer step): the engine skips the filter repack."""
         x = self._check_input(x)
         plan = self.plan_for(x.shape[2:])
         ws = self._workspace(plan)
-        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before)
+        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current)
         self._run_backward(plan, ws, gouts)
         return losses
 
@@ -331,23 +359,25 @@ class UNet3d:
             self._workspaces[key] = sc
         return sc
 
-    def _run_forward_loss(self, plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before):
+    def _run_forward_loss(self, plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current=False):
         """train-mode forward + calc_losses over all levels in ONE engine call (unet_forward_loss): same numbers as forward() then
         loss(), with the coarse levels' loss kernels issued beside the rest of the decoder."""
         if target.dtype != torch.int64 or target.device != self._device:
             raise E.UNetError("target must be an int64 tensor on the model's device")
         target = target.contiguous()
         if any(s[1] == 0 for s in plan.output_shapes) or _NO_FUSED_LOSS:   # a level without a head: the two-call path reports it (train.cpp:664-671)
-            outs = self._run_forward(plan, ws, x, mode=1)
+            outs = self._run_forward(plan, ws, x, mode=1 | (E.MODE_PACKS_CURRENT if packs_current else 0))
             losses, gouts = self.loss(outs, target, cost_ce, cost_dice, cost_mse, collapse_before, plan=plan)
             return outs, losses, gouts
         outs = [torch.empty(s, dtype=torch.float32, device=self._device) for s in plan.output_shapes]
         gouts = [torch.empty_like(o) for o in outs]
         losses = torch.empty(4, dtype=torch.float32, device=self._device)
         mask = (1 if cost_ce else 0) | (2 if cost_dice else 0) | (4 if cost_mse else 0)
-        E.check(E.lib.unet_forward_loss(plan.handle, self._pp, self._bp, x.data_ptr(), E.ptr_array([o.data_ptr() for o in outs]),
-                                        target.data_ptr(), mask, collapse_before, E.ptr_array([g.data_ptr() for g in gouts]),
-                                        losses.data_ptr(), self._loss_scratch(plan).data_ptr(), ws.data_ptr(), _stream_ptr(self._device)))
+        mode = 1 | (E.MODE_PACKS_CURRENT if packs_current else 0)
+        E.check(E.lib.unet_forward_loss_mode(plan.handle, self._pp, self._bp, x.data_ptr(), E.ptr_array([o.data_ptr() for o in outs]),
+                                             target.data_ptr(), mask, collapse_before, E.ptr_array([g.data_ptr() for g in gouts]),
+                                             losses.data_ptr(), self._loss_scratch(plan).data_ptr(), ws.data_ptr(), mode,
+                                             _stream_ptr(self._device)))
         if self._buffers:
             self.num_batches_tracked += 1
         return outs, losses, gouts
