@@ -93,12 +93,12 @@ class Trainer:
         for k, b in enumerate(mine):
             x, t = self.source(cur_data_index + b)
             # the parameters only change at the end of the step (train.cpp:765): this rank's micro-steps 2.. reuse the filter packs of its first
-            cur = self.packs_reuse and k > 0
+            kw = {"packs_current": True} if (self.packs_reuse and k > 0) else {}
             if overlap and k == len(mine) - 1:
                 # gradients accumulate over this rank's micro-steps: only the last backward can hand finished buckets to RCCL
-                losses = m.forward_backward_bucketed(x, t, reduce_bucket, p.cost_ce, p.cost_dice, p.cost_mse, packs_current=cur)
+                losses = m.forward_backward_bucketed(x, t, reduce_bucket, p.cost_ce, p.cost_dice, p.cost_mse, **kw)
             else:
-                losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse, packs_current=cur)
+                losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse, **kw)
             self._stats += losses
             count += 1
         if self.comm is not None:
