@@ -144,6 +144,14 @@ int unet_forward_loss_mode(const unet_plan* plan, const float* const* params, fl
                            const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
                            void* loss_scratch, void* workspace, int mode, void* stream);
 
+/* Gradient buffers of micro-steps that ran side by side (each into a buffer of its own) -> the ONE buffer the step epilogue reads:
+ * out[i] = ((bufs[0][i] + bufs[1][i]) + bufs[2][i]) + ... in fp32, exactly the association a single buffer ends up with when the
+ * micro-steps accumulate into it one after the other (train.cpp:604-606,706: .grad accumulates; 0 + x == x), so the update is
+ * bit-identical to the sequential order.  bufs: host array of n device pointers (n <= UNET_SUM_MAX_BUFFERS; out may be bufs[0]);
+ * all 16-byte aligned, count floats each.  zero_inputs != 0: the inputs other than `out` are cleared for the next step. */
+#define UNET_SUM_MAX_BUFFERS 64
+int unet_sum_buffers(const float* const* bufs, int n, float* out, int64_t count, int zero_inputs, void* stream);
+
 /* step epilogue over flat buffers (train.cpp:759-766 + SGD(momentum, nesterov, weight decay) of
  * unet.cpp:254-275): g *= grad_scale (1/batch_size); coef = min(1, clip_norm/(||g||+1e-6));
  * d = coef*g + wd*p (wd only on decay parameters); m = momentum*m + d; p -= lr*(d + momentum*m) (nesterov)

@@ -7,5 +7,5 @@ set -e
 TAG=${1:-run}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o runc -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o runc -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --batch 0 > $R/gpurun_out/prof_$TAG.log 2>&1
 grep -h '^{' $R/gpurun_out/prof_$TAG.log | tail -1

@@ -1199,6 +1199,19 @@ int unet_forward_loss_mode(const unet_plan* p, const float* const* params, float
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 
+int unet_sum_buffers(const float* const* bufs, int n, float* out, int64_t count, int zero_inputs, void* stream) {
+    try {
+        if (!bufs || !out || n < 1 || n > UNET_SUM_MAX_BUFFERS || count < 0) throw std::runtime_error("unet_sum_buffers: bad argument");
+        for (int k = 0; k < n; ++k)
+            if (!bufs[k] || (reinterpret_cast<uintptr_t>(bufs[k]) & 15)) throw std::runtime_error("unet_sum_buffers: null or misaligned buffer");
+        if (reinterpret_cast<uintptr_t>(out) & 15) throw std::runtime_error("unet_sum_buffers: misaligned output");
+        if (count == 0) return 0;
+        launch_sum_buffers(bufs, n, out, count, zero_inputs, (hipStream_t)stream);
+        check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
 int unet_sgd_step(const unet_plan* p, float* params, float* grads, float* mom, float lr, float momentum, int nesterov, float wd,
                   float clip_norm, float grad_scale, float* norm_out, void* scratch, void* stream) {
     try {

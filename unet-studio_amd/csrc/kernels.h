@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "../../include/unet_augment.h"
+#include "../../include/unet_hip.h"
 
 namespace unet {
 
@@ -122,6 +123,9 @@ void launch_loss_finalize(const float* partial, int nblk, int oc, float level_we
 // pass 3: dlogits = level_weight * d(selected losses)/dlogits
 void launch_loss_grad(const float* logits, const int64_t* target, int C, int64_t S, int collapse, const float* level_out,
                       float level_weight, int cost_mask, float* dlogits, hipStream_t s);
+
+// out = ((b0 + b1) + b2) + ... element-wise in exactly that order (n <= UNET_SUM_MAX_BUFFERS, 16-B aligned); zero_inputs clears b* (not out)
+void launch_sum_buffers(const float* const* bufs, int n, float* out, int64_t count, int zero_inputs, hipStream_t s);
 
 // ---- step epilogue ----
 struct SgdSeg { int64_t offset, count; float wd; };  // wd: 1 when weight decay applies to the tensor, else 0

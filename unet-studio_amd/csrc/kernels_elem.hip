@@ -1127,6 +1127,45 @@ void launch_loss_grad(const float* logits, const int64_t* target, int C, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// out[i] = ((b0[i] + b1[i]) + b2[i]) + ...  (fp32, exactly this association: what ONE buffer holds after the micro-steps have
+// accumulated into it one after the other, since 0 + x == x); optionally clears the inputs for the next optimizer step.
+// The micro-steps of one optimizer step that ran side by side on two streams each wrote a gradient buffer of their own.
+// ------------------------------------------------------------------------------------------------
+struct SumBufs { const float* in[UNET_SUM_MAX_BUFFERS]; int n; };
+__global__ void __launch_bounds__(256) k_sum_buffers(SumBufs b, float* __restrict__ out, int64_t count, int zero_inputs) {
+    for (int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i0 < count; i0 += (int64_t)gridDim.x * 1024) {
+        if (i0 + 3 < count) {
+            float4 acc = *(const float4*)(b.in[0] + i0);
+            for (int k = 1; k < b.n; ++k) {
+                const float4 v = *(const float4*)(b.in[k] + i0);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *(float4*)(out + i0) = acc;
+            if (zero_inputs)
+                for (int k = 0; k < b.n; ++k)
+                    if (b.in[k] != out) *(float4*)(const_cast<float*>(b.in[k]) + i0) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int j = 0; j < 4 && i0 + j < count; ++j) {
+                float acc = b.in[0][i0 + j];
+                for (int k = 1; k < b.n; ++k) acc += b.in[k][i0 + j];
+                out[i0 + j] = acc;
+                if (zero_inputs)
+                    for (int k = 0; k < b.n; ++k)
+                        if (b.in[k] != out) const_cast<float*>(b.in[k])[i0 + j] = 0.f;
+            }
+        }
+    }
+}
+void launch_sum_buffers(const float* const* bufs, int n, float* out, int64_t count, int zero_inputs, hipStream_t s) {
+    SumBufs b;
+    b.n = n;
+    for (int k = 0; k < UNET_SUM_MAX_BUFFERS; ++k) b.in[k] = k < n ? bufs[k] : nullptr;
+    int64_t nb = (count + 1023) / 1024;
+    if (nb > 4096) nb = 4096;
+    k_sum_buffers<<<(unsigned)nb, 256, 0, s>>>(b, out, count, zero_inputs);
+}
+
+// ------------------------------------------------------------------------------------------------
 // step epilogue (train.cpp:759-766, unet.cpp:254-275)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_sumsq_partial(const float* __restrict__ g, int64_t n, float scale, float* __restrict__ partial) {

@@ -290,8 +290,9 @@ class UNet3d:
             self.num_batches_tracked += 1
         return outs
 
-    def _run_backward(self, plan, ws, grad_outs, grad_x=None):
-        pp, gp = self._pp, self._gp
+    def _run_backward(self, plan, ws, grad_outs, grad_x=None, gp=None):
+        """gp: pointer array of a gradient buffer other than flat_grads (grad_pointers), for micro-steps that run side by side"""
+        pp, gp = self._pp, (gp if gp is not None else self._gp)
         go = E.ptr_array([g.data_ptr() if g is not None else None for g in grad_outs])
         E.check(E.lib.unet_backward(plan.handle, pp, go, gp, grad_x.data_ptr() if grad_x is not None else None,
                                     ws.data_ptr(), _stream_ptr(self._device)))
@@ -315,6 +316,32 @@ class UNet3d:
             self._run_backward_part(plan, ws, gouts, op_hi, op_lo)
             on_bucket(int(elem_lo), elem_hi)
             op_hi, elem_hi = op_lo, int(elem_lo)
+        return losses
+
+    def grad_pointers(self, flat):
+        """host array of device pointers (unet_backward's grad_params) into another flat fp32 buffer laid out like flat_grads"""
+        assert flat.numel() == self.flat_grads.numel() and flat.dtype == torch.float32 and flat.device == self._device
+        return E.ptr_array([flat.data_ptr() + 4 * self._offsets[i] for i in range(len(self._params))])
+
+    def make_lane(self, size):
+        """What a micro-step needs for ITSELF to run beside another one of the same optimizer step: a stream, a plan (a plan owns the
+        side stream and the events of its backward: two backwards on ONE plan at a time are not supported, include/unet_hip.h), a
+        workspace and a loss scratch.  The reference runs the batch_size micro-steps of a step on as many threads as it has GPUs
+        (train.cpp:581-606); with one GPU per process the same independence lets two samples share the device, one sample's latency-
+        bound small levels under the other's bandwidth-bound large ones."""
+        key = tuple(int(v) for v in size)
+        plan = E.Plan(self.architecture, self.in_count, self.out_count, key, self._dtype, self._device.index or 0, self._impl)
+        return {"plan": plan, "stream": torch.cuda.Stream(self._device),
+                "ws": torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=self._device),
+                "loss": torch.empty(plan.loss_scratch_bytes, dtype=torch.uint8, device=self._device)}
+
+    def forward_backward_lane(self, lane, x, target, gp, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0, packs_current=False):
+        """forward_backward on a lane (make_lane), on the CURRENT stream, gradients accumulated through the pointer array gp"""
+        x = self._check_input(x)
+        plan, ws = lane["plan"], lane["ws"]
+        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current,
+                                                     loss_scratch=lane["loss"])
+        self._run_backward(plan, ws, gouts, gp=gp)
         return losses
 
     def _check_input(self, x):
@@ -359,7 +386,7 @@ class UNet3d:
             self._workspaces[key] = sc
         return sc
 
-    def _run_forward_loss(self, plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current=False):
+    def _run_forward_loss(self, plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current=False, loss_scratch=None):
         """train-mode forward + calc_losses over all levels in ONE engine call (unet_forward_loss): same numbers as forward() then
         loss(), with the coarse levels' loss kernels issued beside the rest of the decoder."""
         if target.dtype != torch.int64 or target.device != self._device:
@@ -376,7 +403,8 @@ class UNet3d:
         mode = 1 | (E.MODE_PACKS_CURRENT if packs_current else 0)
         E.check(E.lib.unet_forward_loss_mode(plan.handle, self._pp, self._bp, x.data_ptr(), E.ptr_array([o.data_ptr() for o in outs]),
                                              target.data_ptr(), mask, collapse_before, E.ptr_array([g.data_ptr() for g in gouts]),
-                                             losses.data_ptr(), self._loss_scratch(plan).data_ptr(), ws.data_ptr(), mode,
+                                             losses.data_ptr(), (loss_scratch if loss_scratch is not None else self._loss_scratch(plan)).data_ptr(),
+                                             ws.data_ptr(), mode,
                                              _stream_ptr(self._device)))
         if self._buffers:
             self.num_batches_tracked += 1
