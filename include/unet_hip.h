@@ -99,9 +99,10 @@ int unet_profile_end(int max_records, int* op_index, int* category, float* ms, i
  * (NULL entries are skipped).  mode: 0 = eval (bnorm uses running stats: train.cpp:834-840, and after
  * prepare_for_inference y = gamma*x+beta), 1 = train (batch statistics, running stats updated).
  * workspace: unet_plan_workspace_bytes() bytes; after a mode-1 forward it holds what backward needs. */
-/* mode 1 | UNET_MODE_PACKS_CURRENT: as mode 1, and the caller asserts that the filter packs this workspace holds are current -- i.e. a
- * mode-1 forward has run on THIS workspace since the parameters last changed (micro-steps 2..batch_size of one optimizer step,
- * train.cpp:604-606: the parameters only change at :765).  The engine then skips the repack of the bf16 filter images. */
+/* mode | UNET_MODE_PACKS_CURRENT (either mode): the caller asserts that the filter packs this workspace holds are current -- i.e. a
+ * forward OF THE SAME MODE has run on THIS workspace since the parameters last changed (micro-steps 2..batch_size of one optimizer
+ * step, train.cpp:604-606: the parameters only change at :765; volumes 2.. of an inference run, evaluate.cpp:211-246).  The engine
+ * then skips the repack of the filters (the batched bf16 pack, the fp32 engine's per-layer packs). */
 #define UNET_MODE_PACKS_CURRENT 2
 int unet_forward(const unet_plan* plan, const float* const* params, float* const* buffers, const float* x,
                  float* const* outs, void* workspace, int mode, void* stream);

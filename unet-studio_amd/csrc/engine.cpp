@@ -435,7 +435,7 @@ struct Exec {
                         if (!packed)
                             launch_mfma_pack_conv_w(params[op.weight], ws + p.wm_fwd[i],
                                                     (mode == 1 && p.dgrad_mfma[i]) ? ws + p.wm_dgrad[i] : nullptr, cg, s);
-                        if (mode == 1 && !p.dgrad_mfma[i])
+                        if (mode == 1 && !p.dgrad_mfma[i] && !packs_current)
                             launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         const Tensor& T = g.tensors[op.dst];
                         bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
@@ -457,18 +457,21 @@ struct Exec {
                     } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level < 0 &&
                                conv_f32_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
                         // fp32 engine: the same IEEE fp32 products and sums as the VALU kernel below, on the fp32 matrix cores
-                        launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                        if (!packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_f32_mfma(cg, sd, op.nsrc, wf, params[op.bias], (float*)tptr(op.dst), s);
                     } else if (op.kind == OP_CONV) {
-                        launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                        if (!packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
                                                op.out_level >= 0 ? outs[op.out_level] : nullptr, s);
                     } else if (p.use_mfma[i]) {
                         if (!packed) launch_mfma_pack_convt_w(params[op.weight], ws + p.wm_fwd[i], mode == 1 ? ws + p.wm_dgrad[i] : nullptr, cg, s);
                         launch_mfma_convt_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst), s);
                     } else {
-                        launch_pack_convt_w(params[op.weight], wf, wd, op.cin, op.cout, s);
-                        launch_convt_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst), s);
+                        if (!packs_current) launch_pack_convt_w(params[op.weight], wf, wd, op.cin, op.cout, s);
+                        if (p.impl == UNET_IMPL_AUTO && convt_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
+                            launch_convt_f32_mfma(cg, sd, wf, params[op.bias], (float*)tptr(op.dst), s);
+                        else
+                            launch_convt_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst), s);
                     }
                     break;
                 }
@@ -702,6 +705,14 @@ struct Exec {
                     const float* wd = (const float*)(ws + p.w_dgrad[i]);
                     bool any = dg[0].ptr || (op.nsrc > 1 && dg[1].ptr);
                     // parameter gradients: on the side stream now, or held back (see `held`)
+                    // The network's first conv (its input needs no gradient: nothing follows on the caller's stream) -- its weight gradient is
+                    // the last kernel of the backward whichever stream it is on; on the caller's stream it starts without waiting for a fork
+                    // and its reduce is not behind the side stream's queue.  Slab in the op's own region (the shared scratch is the side stream's).
+                    if (!dry && !any && sb != s && op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && p.wz_off[i] != SIZE_MAX &&
+                        conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
+                        ProfScope pw(i, UNET_PROF_WGRAD, s);
+                        launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wz_off[i], s, false);
+                    } else
                     if (!dry) {
                         const int64_t vox = (int64_t)cg.Do * cg.Ho * cg.Wo;
                         if (!deep_seen && vox <= hold_below && !held.empty()) {     // the small levels begin: the held launches run beside them
@@ -712,8 +723,11 @@ struct Exec {
                             issue_pending();
                         } else if (!deep_seen && sb != s && vox >= hold_from) held.push_back(i);
                         else {
+                            // forks are shared among the small levels' layers only (many short launches, the side stream has slack); a layer of
+                            // 32^3 voxels or more forks at once: held back, the encoder's last weight gradients would start after the caller's
+                            // stream has finished and lengthen the tail of the step (time line r07f2: +60 us before the join)
                             pending.push_back(i);
-                            if ((int)pending.size() >= fork_every || sb == s) issue_pending();
+                            if ((int)pending.size() >= fork_every || sb == s || vox >= hold_below) issue_pending();
                         }
                     }
                     if (op.kind == OP_CONV) {
@@ -1404,7 +1418,8 @@ int unet_op_convt_fwd(int dtype, int impl, const void* x, const float* w, const 
             launch_mfma_convt_fwd(g, &sd, 1, wm, b, y, s);
         } else {
             op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
-            launch_convt_fwd_direct(dtype, g, &sd, 1, wf, b, y, s);
+            if (impl == UNET_IMPL_AUTO && convt_f32_mfma_supported(dtype, g, &sd, 1)) launch_convt_f32_mfma(g, &sd, wf, b, (float*)y, s);
+            else launch_convt_fwd_direct(dtype, g, &sd, 1, wf, b, y, s);
         }
     })
 }
@@ -1433,7 +1448,8 @@ int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy,
         SrcDesc sd; sd.ptr = x; sd.C = cin;
         if (impl == UNET_IMPL_AUTO && mfma_convt_wgrad_supported(dtype, g, &sd, 1)) {
             launch_mfma_convt_wgrad(g, &sd, dy, dw, scratch, (hipStream_t)stream);
-            if (db) launch_bias_grad(dtype, dy, cout, (int64_t)g.Do * g.Ho * g.Wo, db, nullptr, (hipStream_t)stream);
+            // (the slab at `scratch` has been reduced by then: the column sums reuse it)
+            if (db) launch_bias_grad(dtype, dy, cout, (int64_t)g.Do * g.Ho * g.Wo, db, scratch, (hipStream_t)stream);
         } else {
             launch_convt_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);
         }

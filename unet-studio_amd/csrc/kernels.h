@@ -231,6 +231,9 @@ void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mf
 bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
                           hipStream_t s);
+// fp32 ConvTranspose3d(k2, s2) forward on the fp32 matrix cores (w_fwd: launch_pack_convt_w's [8][Cin][CoutP])
+bool convt_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+void launch_convt_f32_mfma(const ConvGeom& g, const SrcDesc* src, const float* w_fwd, const float* bias, float* out, hipStream_t s);
 bool wgrad_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t wgrad_f32_mfma_scratch_bytes(const ConvGeom& g);
 void launch_wgrad_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* dy, float* dw, float* db, void* scratch,

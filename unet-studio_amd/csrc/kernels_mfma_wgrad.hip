@@ -704,13 +704,16 @@ static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
         else { c.bz = 4; c.by = 8; c.bx = 4; }
     } else {
         c.pi = 1; c.pj = cbt % 4 == 0 ? 4 : (cbt % 2 == 0 ? 2 : 1);
+        static const int ts12 = getenv("UNET_WGRAD_TS12") ? atoi(getenv("UNET_WGRAD_TS12")) : 0;   // experiment knob: single pairs (tap-split waves)
+        if (ts12 == 1 || (ts12 == 2 && cat * cbt <= 4)) c.pj = 1;
         if (bW >= 12) { c.bz = 2; c.by = 4; c.bx = 16; }
         else if (bW > 4) { c.bz = 2; c.by = 8; c.bx = 8; }
         else { c.bz = 4; c.by = 8; c.bx = 4; }
     }
     c.gy = (cat / c.pi) * (cbt / c.pj);
     int tiles = ((bW + c.bx - 1) / c.bx) * ((bH + c.by - 1) / c.by) * ((bD + c.bz - 1) / c.bz);
-    int want = 512 / c.gy;
+    static const int target = getenv("UNET_WGRAD_BLOCKS") ? atoi(getenv("UNET_WGRAD_BLOCKS")) : 512;   // experiment knob: blocks per launch
+    int want = (kind == 0 ? 512 : target) / c.gy;
     if (want < 1) want = 1;
     c.nsplit = tiles < want ? tiles : want;
     return c;

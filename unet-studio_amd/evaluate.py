@@ -39,6 +39,7 @@ class EvaluateUNet:
 
         try:
             m = self.model
+            packed_sizes = set()                           # volume sizes whose filter packs this run has already made (weights are frozen)
             with torch.no_grad():                          # evaluate.cpp:221
                 while self.cur_prog < len(out) and not self.aborted:
                     self.status = "inferencing"
@@ -48,7 +49,9 @@ class EvaluateUNet:
                             raise E.UNetError("model_io buffer must be (in_count*D, H, W), got %s" % (io.shape,))
                         d = io.shape[0] // m.in_count
                         x = torch.from_numpy(io).view(1, m.in_count, d, io.shape[1], io.shape[2]).to(self.device)
-                        result = m.forward(x)[0]                                         # evaluate.cpp:226-227
+                        size = tuple(x.shape[2:])
+                        result = m.forward(x, packs_current=size in packed_sizes)[0]     # evaluate.cpp:226-227
+                        packed_sizes.add(size)
                         # evaluate.cpp:228-229 copies the logits to the host before the next forward starts; here the copy runs on its
                         # own stream into pinned memory under the next buffer's upload + forward (same bytes, same order of results)
                         done = torch.cuda.Event()

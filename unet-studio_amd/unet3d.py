@@ -351,7 +351,7 @@ class UNet3d:
             raise E.UNetError("input is on %s, model is on %s" % (x.device, self._device))
         return x.to(torch.float32).contiguous()
 
-    def forward(self, x):
+    def forward(self, x, packs_current=False):
         """std::vector<torch::Tensor> forward(torch::Tensor) -- unet.hpp:51, unet.cpp:168-193.
         x: {1,in_count,D,H,W} fp32 on device(); returns one fp32 tensor per decoder level, [0] full resolution.
         In train() mode (and with grad enabled) the outputs carry an autograd edge whose backward
@@ -361,7 +361,9 @@ class UNet3d:
         ws = self._workspace(plan)
         if self._training and torch.is_grad_enabled():
             return list(_Forward.apply(x, self._trigger, self, plan, ws))
-        return self._run_forward(plan, ws, x, mode=1 if self._training else 0)
+        # packs_current (eval loops only): the caller asserts that an eval forward of THIS size has run on this thread since the parameters
+        # last changed, so the filter packs in the workspace are current (UNET_MODE_PACKS_CURRENT)
+        return self._run_forward(plan, ws, x, mode=(1 if self._training else 0) | (E.MODE_PACKS_CURRENT if packs_current else 0))
 
     __call__ = forward
 
