@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/step_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile --no-kernels --batch 0 > $R/gpurun_out/step_$c.log 2>&1
 done
 python3 - "$R" <<'PY'
-import csv, glob, sys, collections, re
+import csv, glob, json, sys, collections, re
 R = sys.argv[1]
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -28,6 +28,10 @@ for k in keys:
     rows.append((fe + wr, fe, wr, tot["FETCH_SIZE"][1][k] / steps, k))
 rows.sort(reverse=True)
 print("HBM bytes per step (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE), MB:  total %.0f" % (sum(r[0] for r in rows) / 1e6))
+# what bench.py's roofline_step reports as counter_bytes (copy gpurun_out/step_hbm_traffic.json to profiles/)
+json.dump({"hbm_bytes_per_step": sum(r[0] for r in rows), "read_bytes_per_step": sum(r[1] for r in rows), "write_bytes_per_step": sum(r[2] for r in rows),
+           "note": "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in passes of their own over 5 whole train steps (128^3 bf16, side stream off), "
+                   "profiles/collect_step_traffic.sh"}, open(R + "/gpurun_out/step_hbm_traffic.json", "w"), indent=1)
 for t, fe, wr, n, k in rows[:40]:
     print("%9.1f MB  read %8.1f  write %8.1f  launches/step %5.1f  %s" % (t / 1e6, fe / 1e6, wr / 1e6, n, k[:70]))
 PY

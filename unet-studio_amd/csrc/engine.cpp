@@ -187,6 +187,10 @@ struct unet_plan {
                         if (pb > pmax) pmax = pb;
                     }
                 }
+                if (conv_f32_mfma_supported(dtype, cg, sd, op.nsrc) && g.tensors[op.dst].norm >= 0) {   // fp64 statistics rows of the fp32 conv
+                    size_t pb = (size_t)conv_f32_mfma_stat_rows(cg, sd) * op.cout * 2 * 8;
+                    if (pb > pmax) pmax = pb;
+                }
                 if (mfma_conv_dgrad_supported(dtype, cg, sd, op.nsrc)) {
                     dgrad_mfma[i] = 1;
                     wm_dgrad[i] = take(mfma_conv_dgrad_w_bytes(cg));
@@ -378,6 +382,7 @@ struct Exec {
         const bool packs_current = (mode & UNET_MODE_PACKS_CURRENT) != 0;
         mode &= 1;
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
+        std::vector<char> fused_dbl(g.norms.size(), 0);     // ... as fp64 rows (the fp32 engine)
         // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
         bool packed = false, pack_pending = false, pack2_pending = false;
         if (p.jobs_dev && packs_current) packed = true;
@@ -458,7 +463,12 @@ struct Exec {
                                conv_f32_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
                         // fp32 engine: the same IEEE fp32 products and sums as the VALU kernel below, on the fp32 matrix cores
                         if (!packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
-                        launch_conv_f32_mfma(cg, sd, op.nsrc, wf, params[op.bias], (float*)tptr(op.dst), s);
+                        const Tensor& T = g.tensors[op.dst];
+                        static const bool no_f32_stats = getenv("UNET_NO_F32_STATS_EPILOGUE") != nullptr;
+                        const bool want_stats = !no_f32_stats && T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
+                        const int rows = launch_conv_f32_mfma(cg, sd, op.nsrc, wf, params[op.bias], (float*)tptr(op.dst), s,
+                                                              want_stats ? (double*)partial() : nullptr);
+                        if (want_stats) { fused_blocks[T.norm] = rows; fused_dbl[T.norm] = 1; }
                     } else if (op.kind == OP_CONV) {
                         if (!packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         launch_conv_fwd_direct(p.dtype, cg, sd, op.nsrc, wf, params[op.bias], tptr(op.dst),
@@ -483,7 +493,7 @@ struct Exec {
                                          stat(op.norm), s);
                     } else {
                         int nb = fused_blocks[op.norm];
-                        bool dbl = false;   // fp32 tensors leave fp64 block partials (k_stats_partial)
+                        bool dbl = fused_dbl[op.norm] != 0;   // fp32 tensors leave fp64 block partials (k_stats_partial, k_conv_f32_mfma)
                         if (!nb) {
                             launch_stats_partial(p.dtype, tptr(n.tensor), n.C, T.voxels(), partial(), s);
                             nb = stats_blocks(T.voxels());
@@ -1315,7 +1325,7 @@ int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const
             launch_conv_first_mfma(g, &sd, w, b, y, nullptr, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
-            if (impl == UNET_IMPL_AUTO && conv_f32_mfma_supported(dtype, g, &sd, 1)) launch_conv_f32_mfma(g, &sd, 1, wf, b, (float*)y, s);
+            if (impl == UNET_IMPL_AUTO && conv_f32_mfma_supported(dtype, g, &sd, 1)) (void)launch_conv_f32_mfma(g, &sd, 1, wf, b, (float*)y, s);
             else launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
         }
     })
@@ -1342,11 +1352,16 @@ int unet_op_conv3d_fwd_fused(int dtype, int impl, const void* x, const float* sc
             if (stats) launch_stats_sum(part, rows, cout, stats, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
-            if (impl == UNET_IMPL_AUTO && conv_f32_mfma_supported(dtype, g, &sd, 1)) launch_conv_f32_mfma(g, &sd, 1, wf, b, (float*)y, s);
-            else launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
-            if (stats) {
-                launch_stats_partial(dtype, y, cout, So, part, s);
-                launch_stats_sum(part, stats_blocks(So), cout, stats, s, dtype == UNET_DTYPE_F32);
+            if (impl == UNET_IMPL_AUTO && conv_f32_mfma_supported(dtype, g, &sd, 1)) {
+                // the fp32 matrix-core conv leaves its own fp64 statistics rows (one per tile)
+                const int rows = launch_conv_f32_mfma(g, &sd, 1, wf, b, (float*)y, s, stats ? (double*)part : nullptr);
+                if (stats) launch_stats_sum(part, rows, cout, stats, s, true);
+            } else {
+                launch_conv_fwd_direct(dtype, g, &sd, 1, wf, b, y, nullptr, s);
+                if (stats) {
+                    launch_stats_partial(dtype, y, cout, So, part, s);
+                    launch_stats_sum(part, stats_blocks(So), cout, stats, s, dtype == UNET_DTYPE_F32);
+                }
             }
         }
     })

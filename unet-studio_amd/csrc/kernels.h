@@ -229,8 +229,11 @@ void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mf
 
 // kernels_mfma_f32.hip: fp32 3x3x3 stride-1 conv on the fp32 matrix cores (the fp32 engine with impl == AUTO)
 bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
-void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
-                          hipStream_t s);
+// stats_partial (optional): [rows][Cout][2] fp64 {sum, sum of squares} of the output per block, rows = the return value
+// (= conv_f32_mfma_stat_rows): the norm layer's statistics without a pass of its own (read them with dbl = true)
+int conv_f32_mfma_stat_rows(const ConvGeom& g, const SrcDesc* src);
+int launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
+                         hipStream_t s, double* stats_partial = nullptr);
 // fp32 ConvTranspose3d(k2, s2) forward on the fp32 matrix cores (w_fwd: launch_pack_convt_w's [8][Cin][CoutP])
 bool convt_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 void launch_convt_f32_mfma(const ConvGeom& g, const SrcDesc* src, const float* w_fwd, const float* bias, float* out, hipStream_t s);

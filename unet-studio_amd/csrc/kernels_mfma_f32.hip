@@ -42,6 +42,10 @@ struct ConvF32Args {
     int dstC[2], dst_acc[2];
     int CoutP;
     int tz, ty, tx;          // tile grid
+    // forward only: per-block {sum, sum of squares} of the block's OUTPUT values per channel, [blockIdx.x][Cout][2] in fp64 -- what
+    // k_stats_partial<float, 0> leaves for an fp32 tensor (ATen's CPU norm kernels accumulate in double, acc_type<float>), so the
+    // norm layer that follows needs no pass of its own over the tensor
+    double* stats;
 };
 
 template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) k_conv_f32_mfma(ConvF32Args a) {
@@ -132,6 +136,33 @@ template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) 
         ocb = co0 - (second ? a.dstC[0] : 0);
         oacc = second ? a.dst_acc[1] : a.dst_acc[0];
     }
+    if (a.stats) {   // wave-uniform
+        __syncthreads();                       // every wave is done with the tiles in LDS
+        double* red = (double*)lds;            // [4 waves][NT][16 co][2]
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < F_BY; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (z < g.Do && y0 + r < g.Ho && x0 + 4 * lq + j < g.Wo) {
+                        const double v = (double)acc[r][n][j];
+                        s1 += v; s2 += v * v;
+                    }
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);      // the four voxel groups (lq) of a channel (lx)
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (lq == 0) { red[((wv * NT + n) * 16 + lx) * 2] = s1; red[((wv * NT + n) * 16 + lx) * 2 + 1] = s2; }
+        }
+        __syncthreads();
+        if (tid < NT * 16) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s1 += red[(w * NT * 16 + tid) * 2]; s2 += red[(w * NT * 16 + tid) * 2 + 1]; }
+            double* o = a.stats + ((int64_t)blockIdx.x * g.Cout + co0 + tid) * 2;
+            o[0] = s1; o[1] = s2;
+        }
+    }
     if (z < g.Do && ob) {
 #pragma unroll
         for (int r = 0; r < F_BY; ++r) {
@@ -168,13 +199,9 @@ template <int S, int BY, int CK, int NT> static void launch_f32_variant(ConvF32A
     k_conv_f32_mfma<S, BY, CK, NT><<<dim3((unsigned)(a.tz * a.ty * a.tx), a.g.Cout / (16 * NT)), 256, lds, s>>>(a);
 }
 
-void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
-                          hipStream_t s) {
-    ConvF32Args a;
-    a.g = g; a.s0 = src[0]; a.s1 = nsrc > 1 ? src[1] : SrcDesc();
-    if (nsrc == 1) a.s0.C = g.Cin;
-    a.w = w_fwd; a.bias = bias; a.out = out; a.CoutP = round_up(g.Cout, 8);
-    a.flip = 0; a.dst[0] = a.dst[1] = nullptr; a.dstC[0] = a.dstC[1] = 0; a.dst_acc[0] = a.dst_acc[1] = 0;
+// which tile the forward uses: 0 = 4x8x16 / 8-channel chunks, 1 = the same with 32 output channels per block, 2 = 4x4x16 / 16-channel
+// chunks (levels with few tiles), 3 / 4 = stride 2 (4x2x16, 16 / 32 output channels per block)
+static int f32_fwd_variant(const ConvGeom& g, const SrcDesc* src) {
     // 32 output channels per block halve the input staging; small volumes take 16 so that twice as many blocks share the walk over Cin
     const int by = g.stride == 1 ? 8 : 2;
     const int64_t tiles = (int64_t)((g.Do + 3) / 4) * ((g.Ho + by - 1) / by) * ((g.Wo + 15) / 16);
@@ -184,14 +211,34 @@ void launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const
     // (0.62 vs 0.68 ms for 32->16).  UNET_F32_TILE=0 keeps the large tile everywhere, =1 forces the small one.
     static const int knob = getenv("UNET_F32_TILE") ? atoi(getenv("UNET_F32_TILE")) : -1;
     const bool few = tiles * (g.Cout / 16) < 2048;
-    if (g.stride == 1 && !wide && g.Cin % 16 == 0 && src[0].C % 16 == 0 && (knob == 1 || (knob < 0 && few))) {
-        launch_f32_variant<1, 4, 16, 1>(a, s);
-        return;
-    }
-    if (g.stride == 1) { if (wide) launch_f32_variant<1, 8, 8, 2>(a, s); else launch_f32_variant<1, 8, 8, 1>(a, s); }
+    if (g.stride == 1 && !wide && g.Cin % 16 == 0 && src[0].C % 16 == 0 && (knob == 1 || (knob < 0 && few))) return 2;
+    if (g.stride == 1) return wide ? 1 : 0;
     // stride 2: 4x2x16 outputs from a 9x5x33 halo in 8-channel chunks (0.37 ms per forward faster than 4x4x16 with 4-channel chunks,
     // whose halo forced twice the chunk passes)
-    else               { if (wide) launch_f32_variant<2, 2, 8, 2>(a, s); else launch_f32_variant<2, 2, 8, 1>(a, s); }
+    return wide ? 4 : 3;
+}
+// rows of the statistics partials the forward leaves (one per tile): plan-time constant
+int conv_f32_mfma_stat_rows(const ConvGeom& g, const SrcDesc* src) {
+    const int v = f32_fwd_variant(g, src);
+    const int by = v == 2 ? 4 : (v >= 3 ? 2 : 8);
+    return ((g.Do + 3) / 4) * ((g.Ho + by - 1) / by) * ((g.Wo + 15) / 16);
+}
+int launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
+                         hipStream_t s, double* stats_partial) {
+    ConvF32Args a;
+    a.g = g; a.s0 = src[0]; a.s1 = nsrc > 1 ? src[1] : SrcDesc();
+    if (nsrc == 1) a.s0.C = g.Cin;
+    a.w = w_fwd; a.bias = bias; a.out = out; a.CoutP = round_up(g.Cout, 8);
+    a.flip = 0; a.dst[0] = a.dst[1] = nullptr; a.dstC[0] = a.dstC[1] = 0; a.dst_acc[0] = a.dst_acc[1] = 0;
+    a.stats = stats_partial;
+    switch (f32_fwd_variant(g, src)) {
+        case 2: launch_f32_variant<1, 4, 16, 1>(a, s); break;
+        case 1: launch_f32_variant<1, 8, 8, 2>(a, s); break;
+        case 0: launch_f32_variant<1, 8, 8, 1>(a, s); break;
+        case 4: launch_f32_variant<2, 2, 8, 2>(a, s); break;
+        default: launch_f32_variant<2, 2, 8, 1>(a, s); break;
+    }
+    return a.tz * a.ty * a.tx;
 }
 
 // ================================================================================================================
@@ -306,7 +353,7 @@ void launch_conv_f32_mfma_dgrad(const ConvGeom& g, const float* dy, const float*
     a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
     a.s0 = SrcDesc(); a.s0.ptr = dy; a.s0.C = g.Cout; a.s1 = SrcDesc();
     a.w = w_dgrad; a.bias = nullptr; a.out = nullptr; a.CoutP = round_up(g.Cin, 8);
-    a.flip = 1;
+    a.flip = 1; a.stats = nullptr;
     for (int k = 0; k < 2; ++k) {
         a.dst[k] = k < ndst ? (float*)dst[k].ptr : nullptr;
         a.dstC[k] = k < ndst ? dst[k].C : 0;
