@@ -296,10 +296,11 @@ struct unet_plan {
             j.slab_off = (long long)(wz_off[i] / 4);
             j.dw_off = p_off[op.weight];
             j.Cb = op.cout;
-            if (op.kind == OP_CONVT) {   // bias gradient of a conv_trans: launch_bias_grad, not part of the slab
+            if (op.kind == OP_CONVT) {   // the bias partials (sums of dy over the fine grid) sit behind the slab, [nsplit][Cout]
                 j.nsplit = mfma_convt_wgrad_splits(cg);
                 j.n = (long long)8 * op.cin * op.cout;
-                j.bias_off = -1; j.db_off = -1;
+                j.bias_off = op.bias >= 0 ? j.slab_off + (long long)j.nsplit * j.n : -1;
+                j.db_off = op.bias >= 0 ? p_off[op.bias] : -1;
             } else {
                 j.nsplit = (op.cin == 1) ? conv_first_wgrad_splits(cg) : mfma_conv_wgrad_splits(cg);
                 j.n = (long long)27 * op.cin * op.cout;
@@ -647,9 +648,8 @@ struct Exec {
                     launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
             } else if (p.wgrad_mfma[i]) {
                 const bool defer = gflat && p.wz_job_of_op[i] >= 0;
-                launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer, gparams[op.bias]);
                 if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
-                launch_bias_grad(p.dtype, gptr(t), cg.Cout, (int64_t)cg.Do * cg.Ho * cg.Wo, gparams[op.bias], ws + p.wgrad_off, sb);
             } else {
                 launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
             }
@@ -1462,9 +1462,7 @@ int unet_op_convt_bwd_weight(int dtype, int impl, const void* x, const void* dy,
         ConvGeom g = op_geom(cin, cout, D, H, W, 2, 2, true);
         SrcDesc sd; sd.ptr = x; sd.C = cin;
         if (impl == UNET_IMPL_AUTO && mfma_convt_wgrad_supported(dtype, g, &sd, 1)) {
-            launch_mfma_convt_wgrad(g, &sd, dy, dw, scratch, (hipStream_t)stream);
-            // (the slab at `scratch` has been reduced by then: the column sums reuse it)
-            if (db) launch_bias_grad(dtype, dy, cout, (int64_t)g.Do * g.Ho * g.Wo, db, scratch, (hipStream_t)stream);
+            launch_mfma_convt_wgrad(g, &sd, dy, dw, scratch, (hipStream_t)stream, false, db);
         } else {
             launch_convt_wgrad_direct(dtype, g, &sd, 1, dy, dw, db, nullptr, (hipStream_t)stream);
         }

@@ -201,11 +201,12 @@ bool wgrad_small_supported(const ConvGeom& g, int nsrc);
 size_t wgrad_small_scratch_bytes(const ConvGeom& g);
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,
                              void* scratch, hipStream_t s);
-// conv_trans wgrad (single source); bias grad separately (launch_bias_grad)
+// conv_trans wgrad (single source); db (optional): the bias gradient rides along (sums of dy as the kernel stages it: [rows][Cout]
+// partials behind the slab, or += db itself in the direct form) -- no pass of its own over dy
 bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s,
-                             bool defer_reduce = false);
+                             bool defer_reduce = false, float* db = nullptr);
 // vectorised per-block column sums partial[blk][C] of a bf16 [S][C] tensor; returns #blocks (0: not applicable)
 int launch_colsum_partial8(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s);
 size_t bias_grad_scratch_bytes(int C, int64_t S);

@@ -34,6 +34,7 @@ struct MfmaWgradArgs {
     // `bias_slab` the bias gradient; the block ADDS its result to them (.grad accumulates) -- no slab, no reduce pass.  Every
     // gradient element belongs to exactly one block and is summed in a fixed order, so the result stays bit-reproducible.
     int direct;
+    int bias_from_a;   // conv_trans: bias_slab holds per-channel sums of the HALO-side tensor (dy), [nsplit][Ca]
 };
 
 __device__ __forceinline__ bf16x8 tr_read2(const char* p0, const char* p1) {
@@ -87,7 +88,11 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
     const char* abase = (const char*)(sa ? a.asrc[1].ptr : a.asrc[0].ptr) + (size_t)cla * 2;
     const int cb = (coB + (ub >> 1)) * 16 + (ub & 1) * 8;
     const char* bbase = (const char*)a.bsrc.ptr + (size_t)cb * 2;
-    const bool do_bias = a.bias_slab != nullptr && ciB == 0;
+    const bool do_bias = a.bias_slab != nullptr && ciB == 0 && !a.bias_from_a;
+    // conv_trans: dL/dbias = sum over the FINE grid of dy, which is this kernel's halo side; with a 2x2x2 stride-2 window the halo
+    // tiles cover the fine grid exactly once, so the blocks of cb-tile 0 sum the A units they stage (threads with equal tid % GA hold
+    // the same 8 channels, as the B side does for conv)
+    const bool do_bias_a = a.bias_slab != nullptr && coB == 0 && a.bias_from_a;
 
     // staging units of this thread, decoded once: coordinates (z 4 bits | y 5 << 4 | x 6 << 9) | LDS offset / 16 << 15 (or -1),
     // and the voxel offset from the tile's origin in the source volume (address = tile base + offset * voxel stride)
@@ -134,7 +139,16 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
             }
             bf16x8 v = zero8;
             if (ok) v = *(const bf16x8*)(at + __umul24(ua_vox[itr], avs));
-            if constexpr (DIRECT) { if ((itr + 1) * 256 <= UNITS_A || uc >= 0) *(bf16x8*)(smem + ((uc >> 15) << 4)) = v; }
+            if constexpr (DIRECT) {
+                if ((itr + 1) * 256 <= UNITS_A || uc >= 0) {
+                    *(bf16x8*)(smem + ((uc >> 15) << 4)) = v;
+                    if (do_bias_a) {
+                        const uint4 w = __builtin_bit_cast(uint4, v);
+                        bsum[0] += bf_lo(w.x); bsum[1] += bf_hi(w.x); bsum[2] += bf_lo(w.y); bsum[3] += bf_hi(w.y);
+                        bsum[4] += bf_lo(w.z); bsum[5] += bf_hi(w.z); bsum[6] += bf_lo(w.w); bsum[7] += bf_hi(w.w);
+                    }
+                }
+            }
             else RA[itr] = v;
         }
 #pragma unroll
@@ -162,7 +176,14 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
     auto commit = [&]() {
 #pragma unroll
         for (int itr = 0; itr < ITERS_A; ++itr)
-            if ((itr + 1) * 256 <= UNITS_A || ua_pk[itr] >= 0) *(bf16x8*)(smem + ((ua_pk[itr] >> 15) << 4)) = RA[itr];
+            if ((itr + 1) * 256 <= UNITS_A || ua_pk[itr] >= 0) {
+                *(bf16x8*)(smem + ((ua_pk[itr] >> 15) << 4)) = RA[itr];
+                if (do_bias_a) {
+                    const uint4 v = __builtin_bit_cast(uint4, RA[itr]);
+                    bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+                    bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+                }
+            }
 #pragma unroll
         for (int itr = 0; itr < ITERS_B; ++itr) {
             if ((itr + 1) * 256 <= UNITS_B || ub_pk[itr] >= 0) {
@@ -342,31 +363,33 @@ __global__ void __launch_bounds__(256, 2) k_mfma_wgrad(MfmaWgradArgs a) {   // <
         }
     }
     }
-    if (do_bias) {
-        // threads with equal tid % GB hold partial sums of the same 8 channels: shuffle tree inside each wave (lanes GB apart), then the
-        // four wave totals through LDS (the serial loop over 256 / GB LDS values per output cost ~6 us at the end of every block)
+    if (do_bias || do_bias_a) {
+        // threads with equal tid % GU hold partial sums of the same 8 channels (GU = the side's staging roles): shuffle tree inside each
+        // wave (lanes GU apart), then the four wave totals through LDS (the serial loop over 256 / GU LDS values per output cost ~6 us
+        // at the end of every block)
+        const int GU = do_bias_a ? GA : GB;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = bsum[e];
-#pragma unroll
-            for (int m = GB; m < 64; m <<= 1) v += __shfl_xor(v, m);
+            for (int m = GU; m < 64; m <<= 1) v += __shfl_xor(v, m);
             bsum[e] = v;
         }
         __syncthreads();
-        float* bred = (float*)smem;   // [4 waves][GB][8]
-        if (lane < GB) {
+        float* bred = (float*)smem;   // [4 waves][GU][8]
+        if (lane < GU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bred[(wave * GB + lane) * 8 + e] = bsum[e];
+            for (int e = 0; e < 8; ++e) bred[(wave * GU + lane) * 8 + e] = bsum[e];
         }
         __syncthreads();
-        if (tid < GB * 8) {
+        if (tid < GU * 8) {
             int u = tid / 8, e = tid % 8;
             float sacc = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) sacc += bred[(w * GB + u) * 8 + e];
-            int c = (coB + (u >> 1)) * 16 + (u & 1) * 8 + e;
-            if (a.direct) a.bias_slab[c] += sacc;     // the bias gradient itself (one block per channel: ciB == 0)
-            else a.bias_slab[(size_t)blockIdx.x * g.Cout + c] = sacc;
+            for (int w = 0; w < 4; ++w) sacc += bred[(w * GU + u) * 8 + e];
+            const int nC = do_bias_a ? g.Cin : g.Cout;      // channels of the summed side (conv_trans: the kernel's Cin = the layer's Cout)
+            int c = ((do_bias_a ? ciB : coB) + (u >> 1)) * 16 + (u & 1) * 8 + e;
+            if (a.direct) a.bias_slab[c] += sacc;     // the bias gradient itself (exactly one block per channel)
+            else a.bias_slab[(size_t)blockIdx.x * nC + c] = sacc;
         }
     }
 }
@@ -725,7 +748,7 @@ size_t mfma_wgrad_scratch_bytes(const ConvGeom& g) {
 }
 size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g) {
     WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
-    return (size_t)c.nsplit * 8 * g.Cin * g.Cout * 4 + 256;
+    return ((size_t)c.nsplit * 8 * g.Cin * g.Cout + (size_t)c.nsplit * g.Cout) * 4 + 256;
 }
 
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int PI, int PJ>
@@ -785,6 +808,7 @@ void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, con
     MfmaWgradArgs a;
     a.g = g; a.nasrc = nsrc; a.asrc[0] = src[0]; if (nsrc > 1) a.asrc[1] = src[1];
     a.bsrc = SrcDesc(); a.bsrc.ptr = dy; a.bsrc.C = g.Cout;
+    a.bias_from_a = 0;
     a.slab = (float*)scratch;
     a.bias_slab = db ? a.slab + (size_t)c.nsplit * 27 * g.Cin * g.Cout : nullptr;
     a.tiles_x = a.tiles_y = a.tiles_z = 0;
@@ -810,17 +834,21 @@ void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, con
 
 // conv_trans wgrad (g = forward geometry of the conv_trans: D,H,W coarse input, Do,Ho,Wo fine output).
 // halo side A = dy (fine, Cout channels), tile side B = transformed input (coarse, Cin channels): D_t[co][ci].
-void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s, bool defer_reduce) {
+void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s, bool defer_reduce,
+                             float* db) {
     WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
     MfmaWgradArgs a;
+    a.bias_from_a = 1;
     a.g.Cin = g.Cout; a.g.Cout = g.Cin; a.g.D = g.Do; a.g.H = g.Ho; a.g.W = g.Wo; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;
     a.g.ks = 2; a.g.stride = 2;
     a.nasrc = 1; a.asrc[0] = SrcDesc(); a.asrc[0].ptr = dy; a.asrc[0].C = g.Cout;
     a.bsrc = src[0];
-    a.slab = (float*)scratch; a.bias_slab = nullptr;
+    a.slab = (float*)scratch;
+    // the bias gradient rides along (sums of dy as it is staged): [nsplit][Cout] behind the slab
+    a.bias_slab = db ? a.slab + (size_t)c.nsplit * 8 * g.Cin * g.Cout : nullptr;
     a.tiles_x = a.tiles_y = a.tiles_z = 0;
     if (c.direct) {
-        a.slab = dw;
+        a.slab = dw; a.bias_slab = db;
         if (c.bx == 4) launch_wgrad_cfg<2, 2, 0, 4, 4, 4, 1, 1>(a, c, s);
         else launch_wgrad_cfg<2, 2, 0, 2, 8, 8, 1, 1>(a, c, s);
         return;
@@ -829,7 +857,7 @@ void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* 
     else if (g.W > 4) launch_wgrad_p<2, 2, 0, 2, 8, 8>(a, c, s);
     else launch_wgrad_p<2, 2, 0, 4, 8, 4>(a, c, s);
     // slab[cb = ci][ca = co][t] = the layout of dw ([Cin][Cout][2][2][2])
-    if (!defer_reduce) wgrad_reduce(a.slab, nullptr, c.nsplit, (int64_t)8 * g.Cin * g.Cout, g.Cin, dw, nullptr, s);
+    if (!defer_reduce) wgrad_reduce(a.slab, a.bias_slab, c.nsplit, (int64_t)8 * g.Cin * g.Cout, g.Cout, dw, db, s);
 }
 
 }  // namespace unet
