@@ -143,3 +143,47 @@ def test_cpp_host_reads_and_writes_the_same_files(tmp_path):
     back = nz.load_from_file(fout, HostModel)
     for x, y in zip(back.parameters(), m.parameters()):
         assert torch.equal(x, y)
+
+
+def _corrupt_files(tmp_path):
+    """crafted / damaged network files: a header that declares 2^31-1 x 2^31-1 doubles, a payload cut short, a negative type code,
+    channels with one element, garbage that is not gzip"""
+    import struct
+    m = _model()
+    good = str(tmp_path / "good.nz")
+    assert nz.save_to_file(m, good)
+    raw = gzip.open(good, "rb").read()
+    files = {}
+
+    def put(name, payload):
+        f = str(tmp_path / (name + ".nz"))
+        with gzip.open(f, "wb") as g:
+            g.write(payload)
+        files[name] = f
+    put("huge", struct.pack("<5i", 0, 2 ** 31 - 1, 2 ** 31 - 1, 0, 9) + b"channels\0" + b"\0" * 64)
+    put("truncated", raw[: len(raw) // 2])
+    put("negative_type", struct.pack("<5i", -10, 1, 2, 0, 9) + b"channels\0" + b"\0" * 8)
+    put("short_channels", struct.pack("<5i", 20, 1, 1, 0, 9) + b"channels\0" + struct.pack("<i", 1) + raw[raw.index(b"architecture") - 20:])
+    f = str(tmp_path / "notgzip.nz")
+    open(f, "wb").write(b"this is not a gzip stream")
+    files["notgzip"] = f
+    return files
+
+
+def test_damaged_files_are_refused_with_a_message_by_the_python_reader(tmp_path):
+    for name, f in _corrupt_files(tmp_path).items():
+        with pytest.raises(nz.NzError):
+            nz.load_from_file(f, HostModel)
+
+
+def test_damaged_files_are_refused_with_a_message_by_the_cpp_reader(tmp_path):
+    """load_from_file's contract (main.cpp:157-206) is `false + error_msg`, never an exception: a crafted header must not reach
+    std::vector::resize with 2^65 bytes, a short stream must fail on the read, the gzFile must not leak (ASan run: sanitize_host.sh)"""
+    exe = os.path.join(PKG, "test_nz_io")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(PKG, "csrc", "build_host.sh")])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = PKG + ":" + os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    for name, f in _corrupt_files(tmp_path).items():
+        r = subprocess.run([exe, f, str(tmp_path / "out.nz")], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and "LOAD FAILED" in r.stdout, (name, r.returncode, r.stdout[-300:], r.stderr[-300:])

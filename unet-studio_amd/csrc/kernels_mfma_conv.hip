@@ -1356,7 +1356,10 @@ bool conv_first_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src,
 }
 int conv_first_mfma_blocks(const ConvGeom& g) {
     int tiles = ((g.W + 15) / 16) * ((g.H + 7) / 8) * ((g.D + 3) / 4);
-    return tiles < 512 ? tiles : 512;
+    // 73 VGPRs (Cout 16) allow 6 blocks per CU; the kernel is a per-wave latency chain (LDS gathers -> MFMA -> store), so the grid, not
+    // the registers, set its occupancy at the round-2 value of 512 (UNET_CONV_FIRST_BLOCKS: experiment knob)
+    static const int want = getenv("UNET_CONV_FIRST_BLOCKS") ? atoi(getenv("UNET_CONV_FIRST_BLOCKS")) : 512;
+    return tiles < want ? tiles : want;
 }
 int launch_conv_first_mfma(const ConvGeom& g, const SrcDesc* src, const float* w, const float* bias, void* out, float* stats_partial,
                            hipStream_t s) {

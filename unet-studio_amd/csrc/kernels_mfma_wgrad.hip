@@ -663,7 +663,8 @@ bool conv_first_wgrad_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc
 }
 static int first_wgrad_blocks(const ConvGeom& g) {
     int tiles = ((g.W + 31) / 32) * ((g.H + 7) / 8) * ((g.D + 1) / 2);
-    return tiles < 512 ? tiles : 512;
+    static const int want = getenv("UNET_WGRAD_FIRST_BLOCKS") ? atoi(getenv("UNET_WGRAD_FIRST_BLOCKS")) : 512;   // experiment knob
+    return tiles < want ? tiles : want;
 }
 size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g) { return (size_t)first_wgrad_blocks(g) * (27 * g.Cout + g.Cout) * 4 + 256; }
 // dw += , db += (db may be null); scratch: conv_first_wgrad_mfma_scratch_bytes

@@ -44,5 +44,19 @@ from unet_studio_amd import nz
 assert nz.save_to_file(test_nz._model(), sys.argv[1] + "/py.nz")
 PY
 LD_LIBRARY_PATH=$T/lib:$LD_LIBRARY_PATH unet-studio_amd/csrc/build/asan/test_nz_io $TMP/py.nz $TMP/cpp.nz | tail -1
+echo "== damaged files through the C++ reader under ASan + UBSan (must fail with a message: no exception, no leak of the gzFile) =="
+python3 - "$TMP" <<'PY'
+import gzip, struct, sys
+d = sys.argv[1]
+raw = gzip.open(d + "/py.nz", "rb").read()
+gzip.open(d + "/truncated.nz", "wb").write(raw[: len(raw) // 2])
+gzip.open(d + "/huge.nz", "wb").write(struct.pack("<5i", 0, 2 ** 31 - 1, 2 ** 31 - 1, 0, 9) + b"channels\0" + b"\0" * 64)
+open(d + "/notgzip.nz", "wb").write(b"this is not a gzip stream")
+PY
+for f in truncated huge notgzip; do
+    if LD_LIBRARY_PATH=$T/lib:$LD_LIBRARY_PATH unet-studio_amd/csrc/build/asan/test_nz_io $TMP/$f.nz $TMP/out.nz > $TMP/$f.log 2>&1; then echo "$f.nz was accepted"; exit 1; fi
+    grep -q "LOAD FAILED" $TMP/$f.log || { echo "$f.nz: no clean failure"; cat $TMP/$f.log; exit 1; }
+done
+echo "damaged files refused cleanly"
 rm -rf "$TMP"
 echo "sanitize_host: clean"
