@@ -187,6 +187,10 @@ struct unet_plan {
                         if (pb > pmax) pmax = pb;
                     }
                 }
+                if (conv_first_f32_mfma_supported(dtype, cg, sd, op.nsrc) && g.tensors[op.dst].norm >= 0) {
+                    size_t pb = (size_t)conv_first_f32_mfma_blocks(cg) * op.cout * 2 * 8;
+                    if (pb > pmax) pmax = pb;
+                }
                 if (conv_f32_mfma_supported(dtype, cg, sd, op.nsrc) && g.tensors[op.dst].norm >= 0) {   // fp64 statistics rows of the fp32 conv
                     size_t pb = (size_t)conv_f32_mfma_stat_rows(cg, sd) * op.cout * 2 * 8;
                     if (pb > pmax) pmax = pb;
@@ -459,6 +463,15 @@ struct Exec {
                         int rows = launch_conv_first_mfma(cg, sd, params[op.weight], params[op.bias], tptr(op.dst),
                                                           want_stats ? partial() : nullptr, s);
                         if (want_stats) fused_blocks[T.norm] = rows;
+                        if (mode == 1 && !packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                    } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level < 0 &&
+                               conv_first_f32_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
+                        // fp32 engine, Cin = 1: the first conv on the fp32 matrix cores (filter read in torch layout), statistics in its epilogue
+                        const Tensor& T = g.tensors[op.dst];
+                        const bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
+                        const int rows = launch_conv_first_f32_mfma(cg, sd, params[op.weight], params[op.bias], (float*)tptr(op.dst),
+                                                                    want_stats ? (double*)partial() : nullptr, s);
+                        if (want_stats) { fused_blocks[T.norm] = rows; fused_dbl[T.norm] = 1; }
                         if (mode == 1 && !packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                     } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level < 0 &&
                                conv_f32_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
@@ -1323,6 +1336,8 @@ int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const
             launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, nullptr, s);
         } else if (impl == UNET_IMPL_AUTO && conv_first_mfma_supported(dtype, g, &sd, 1)) {
             launch_conv_first_mfma(g, &sd, w, b, y, nullptr, s);
+        } else if (impl == UNET_IMPL_AUTO && conv_first_f32_mfma_supported(dtype, g, &sd, 1)) {
+            (void)launch_conv_first_f32_mfma(g, &sd, w, b, (float*)y, nullptr, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
             if (impl == UNET_IMPL_AUTO && conv_f32_mfma_supported(dtype, g, &sd, 1)) (void)launch_conv_f32_mfma(g, &sd, 1, wf, b, (float*)y, s);

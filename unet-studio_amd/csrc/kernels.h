@@ -235,6 +235,12 @@ bool conv_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, i
 int conv_f32_mfma_stat_rows(const ConvGeom& g, const SrcDesc* src);
 int launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const float* w_fwd, const float* bias, float* out,
                          hipStream_t s, double* stats_partial = nullptr);
+// the fp32 engine's first conv (Cin = 1, 3x3x3 stride 1, Cout 16 or 32, plain fp32 input) on the fp32 matrix cores, filter read in torch
+// layout; stats_partial (optional): fp64 {sum, sum of squares} rows, one per block (the return value)
+bool conv_first_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
+int conv_first_f32_mfma_blocks(const ConvGeom& g);
+int launch_conv_first_f32_mfma(const ConvGeom& g, const SrcDesc* src, const float* w, const float* bias, float* out, double* stats_partial,
+                               hipStream_t s);
 // fp32 ConvTranspose3d(k2, s2) forward on the fp32 matrix cores (w_fwd: launch_pack_convt_w's [8][Cin][CoutP])
 bool convt_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 void launch_convt_f32_mfma(const ConvGeom& g, const SrcDesc* src, const float* w_fwd, const float* bias, float* out, hipStream_t s);

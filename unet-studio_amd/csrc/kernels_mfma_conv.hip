@@ -1166,7 +1166,8 @@ static int tile_count(const ConvGeom& g, Tile t) { return ((g.Wo + t.bx - 1) / t
 // small volumes (the deep levels) get small tiles so that tiles x row-tiles still covers the chip
 static bool small_s1k3(const ConvGeom& g, int CK) {   // few big tiles: the volume is small, use k_mfma_conv_small (CK 32)
     Tile big = g.Wo >= 12 ? (CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16}) : (g.Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4});
-    return (int64_t)tile_count(g, big) * (g.Cout / 16) < 256;
+    static const int below = getenv("UNET_SMALL_BELOW") ? atoi(getenv("UNET_SMALL_BELOW")) : 256;   // experiment knob
+    return (int64_t)tile_count(g, big) * (g.Cout / 16) < below;
 }
 static Tile tile_s1k3(const ConvGeom& g, int CK) {
     Tile big = g.Wo >= 12 ? (CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16}) : (g.Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4});

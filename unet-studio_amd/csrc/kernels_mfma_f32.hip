@@ -48,7 +48,7 @@ struct ConvF32Args {
     double* stats;
 };
 
-template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) k_conv_f32_mfma(ConvF32Args a) {
+template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256, 2) k_conv_f32_mfma(ConvF32Args a) {
     typedef F32Tile<S, BY, CK> TL;
     constexpr int F_BY = BY, F_CK = CK, F_HY = TL::HY, F_HX = TL::HX, F_HV = TL::HV, F_PS = TL::PS;
     extern __shared__ float lds[];
@@ -70,23 +70,52 @@ template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) 
         for (int r = 0; r < F_BY; ++r) acc[r][n] = f32x4{b, b, b, b};
     }
 
-    for (int c0 = 0; c0 < g.Cin; c0 += F_CK) {
-        // which source holds channels [c0, c0+8): selects, not an indexed array of descriptors (that would live in scratch)
+    // The next chunk's global loads ride in registers through this chunk's MFMAs (round 3): the loop used to be load -> LDS ->
+    // barrier -> 432 MFMAs per chunk with every load latency exposed (~2 of ~9 us per chunk and block at 128^3).
+    constexpr int ITX = (F_HV * (F_CK / 4) + 255) / 256;        // halo float4 per thread and chunk
+    constexpr int ITW = (27 * F_CK * 4 * NT + 255) / 256;       // filter float4 per thread and chunk
+    float4 XR[ITX], WR[ITW];
+    unsigned xin = 0;                                           // bit i: unit i lies inside the volume (zero padding applies AFTER the transform)
+    auto fetch = [&](int c0) {
         const bool second = c0 >= a.s0.C;
         const float* sp = (const float*)(second ? a.s1.ptr : a.s0.ptr);
         const int sC = second ? a.s1.C : a.s0.C, cb = second ? c0 - a.s0.C : c0;
-        const float* sc = second ? a.s1.scale : a.s0.scale;
-        const float* sh = second ? a.s1.shift : a.s0.shift;
-        const int act = second ? a.s1.act : a.s0.act;
-        __syncthreads();   // the previous chunk's MFMAs have read xs / wsm
-        for (int it = tid; it < F_HV * (F_CK / 4); it += 256) {
+        xin = 0;
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            const int it = tid + i * 256;
             const int hv = it / (F_CK / 4), q = it % (F_CK / 4);
             const int hz = hv / (F_HY * F_HX), rem = hv - hz * (F_HY * F_HX), hy = rem / F_HX, hx = rem - hy * F_HX;
             const int iz = z0 * S + hz - 1, iy = y0 * S + hy - 1, ix = x0 * S + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+            XR[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < F_HV * (F_CK / 4) && iz >= 0 && iz < g.D && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) {
+                XR[i] = *(const float4*)(sp + (((int64_t)iz * g.H + iy) * g.W + ix) * sC + cb + q * 4);
+                xin |= 1u << i;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ITW; ++i) {
+            const int it = tid + i * 256;
+            const int c4 = it % (4 * NT), rk = it / (4 * NT), k = rk % F_CK, tap = rk / F_CK;
+            WR[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < 27 * F_CK * 4 * NT)
+                WR[i] = *(const float4*)(a.w + ((int64_t)(a.flip ? 26 - tap : tap) * g.Cin + c0 + k) * a.CoutP + co0 + c4 * 4);
+        }
+    };
+    auto commit = [&](int c0) {
+        const bool second = c0 >= a.s0.C;
+        const int cb = second ? c0 - a.s0.C : c0;
+        const float* sc = second ? a.s1.scale : a.s0.scale;
+        const float* sh = second ? a.s1.shift : a.s0.shift;
+        const int act = second ? a.s1.act : a.s0.act;
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            const int it = tid + i * 256;
+            if (it >= F_HV * (F_CK / 4)) continue;
+            const int hv = it / (F_CK / 4), q = it % (F_CK / 4);
+            float4 v = XR[i];
+            if ((xin >> i) & 1u) {
                 const int c = cb + q * 4;
-                v = *(const float4*)(sp + (((int64_t)iz * g.H + iy) * g.W + ix) * sC + c);
                 if (sc) {
                     const float4 s4 = *(const float4*)(sc + c), h4 = *(const float4*)(sh + c);
                     v.x = v.x * s4.x + h4.x; v.y = v.y * s4.y + h4.y; v.z = v.z * s4.z + h4.z; v.w = v.w * s4.w + h4.w;
@@ -96,13 +125,21 @@ template <int S, int BY, int CK, int NT> __global__ void __launch_bounds__(256) 
             float* d = xs + (q * 4) * F_PS + hv;
             d[0] = v.x; d[F_PS] = v.y; d[2 * F_PS] = v.z; d[3 * F_PS] = v.w;
         }
-        for (int it = tid; it < 27 * F_CK * 4 * NT; it += 256) {   // float4 = 4 cout of one (tap, cin)
+#pragma unroll
+        for (int i = 0; i < ITW; ++i) {
+            const int it = tid + i * 256;
+            if (it >= 27 * F_CK * 4 * NT) continue;
             const int c4 = it % (4 * NT), rk = it / (4 * NT), k = rk % F_CK, tap = rk / F_CK;
-            const float4 v = *(const float4*)(a.w + ((int64_t)(a.flip ? 26 - tap : tap) * g.Cin + c0 + k) * a.CoutP + co0 + c4 * 4);
             const int n = c4 >> 2, cc = (c4 & 3) * 4;
-            *(float4*)(wsm + ((n * 27 + tap) * F_CK + k) * 16 + cc) = v;
+            *(float4*)(wsm + ((n * 27 + tap) * F_CK + k) * 16 + cc) = WR[i];
         }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < g.Cin; c0 += F_CK) {
+        __syncthreads();   // the previous chunk's MFMAs have read xs / wsm
+        commit(c0);
         __syncthreads();
+        if (c0 + F_CK < g.Cin) fetch(c0 + F_CK);     // in flight during the MFMAs below
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
@@ -239,6 +276,131 @@ int launch_conv_f32_mfma(const ConvGeom& g, const SrcDesc* src, int nsrc, const 
         default: launch_f32_variant<2, 2, 8, 1>(a, s); break;
     }
     return a.tz * a.ty * a.tx;
+}
+
+// ================================================================================================================
+// The network's first conv in fp32 (Cin = 1, 3x3x3, stride 1, Cout = 16 * NT) on the fp32 matrix cores: K = the 27 taps padded to 28,
+//     y[voxel][co] = bias[co] + sum_tap x[voxel + tap] * w[co][tap]          M = 16 voxels of one x-row, N = 16 co, K = 4 taps
+// Tile 4 x 8 x 16 voxels, halo 6 x 10 x 18 floats in LDS; a lane gathers its tap of the k-step with one 4-byte LDS read, the 7 x NT
+// filter operands sit in registers.  Output-bound (64 B per voxel written for 4 B read); replaces the VALU k_conv_first<float> (0.20 ms
+// of the fp32 forward at 128^3) and leaves the norm statistics of its output (fp64 rows per block) like k_conv_f32_mfma.
+// ================================================================================================================
+namespace {
+struct ConvFirstF32Args {
+    ConvGeom g;
+    const float* x;      // [D][H][W]
+    const float* w;      // [Cout][27] (torch layout, Cin = 1)
+    const float* bias;
+    float* out;          // [D][H][W][Cout]
+    double* stats;       // [gridDim.x][Cout][2] or nullptr
+    int tiles_x, tiles_y, tiles_z;
+};
+template <int NT> __global__ void __launch_bounds__(256) k_conv_first_f32_mfma(ConvFirstF32Args a) {
+    constexpr int BZ = 4, BY = 8, BX = 16, HZ = BZ + 2, HY = BY + 2, HX = BX + 2, NV = HZ * HY * HX, ITERS = (NV + 255) / 256;
+    __shared__ float tile[NV];
+    __shared__ double red[4 * NT * 16 * 2];
+    const ConvGeom& g = a.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lx = lane & 15, lq = lane >> 4;
+    const int ntiles = a.tiles_x * a.tiles_y * a.tiles_z;
+    // B operands: lane (k = lq, col = lx) of k-step s <- w[co = n*16 + lx][tap = 4 s + lq]; A addresses: tap -> offset inside the tile
+    float wb[7][NT];
+    int aoff[7];
+#pragma unroll
+    for (int st = 0; st < 7; ++st) {
+        const int tap = 4 * st + lq;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wb[st][n] = tap < 27 ? a.w[(n * 16 + lx) * 27 + tap] : 0.f;
+        const int tp = tap < 27 ? tap : 26;     // the padding tap reads a finite value (times a zero filter operand)
+        aoff[st] = (((tp / 9) + wave) * HY + (tp / 3) % 3) * HX + tp % 3 + lx;
+    }
+    float bcol[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bcol[n] = a.bias ? a.bias[n * 16 + lx] : 0.f;
+    double s1[NT], s2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { s1[n] = 0.0; s2[n] = 0.0; }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int x0 = (t % a.tiles_x) * BX, y0 = ((t / a.tiles_x) % a.tiles_y) * BY, z0 = (t / (a.tiles_x * a.tiles_y)) * BZ;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITERS; ++k) {
+            const int u = tid + k * 256;
+            if (u < NV) {
+                const int hz = u / (HY * HX), hr = u % (HY * HX), hy = hr / HX, hx = hr % HX;
+                const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                tile[u] = ((unsigned)gz < (unsigned)g.D && (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W)
+                              ? a.x[((size_t)gz * g.H + gy) * g.W + gx] : 0.f;
+            }
+        }
+        __syncthreads();
+        const int gz = z0 + wave;
+#pragma unroll
+        for (int i = 0; i < BY; ++i) {            // m-tile = row i of z-plane `wave`: 16 voxels along x
+            f32x4 acc[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = f32x4{bcol[n], bcol[n], bcol[n], bcol[n]};
+#pragma unroll
+            for (int st = 0; st < 7; ++st) {
+                const float av = tile[aoff[st] + i * HX];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wb[st][n], acc[n], 0, 0, 0);
+            }
+            const int gy = y0 + i;
+            if (gz < g.D && gy < g.H) {
+                float* o = a.out + (((size_t)gz * g.H + gy) * g.W) * g.Cout + lx;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int gx = x0 + 4 * lq + j;
+                    if (gx < g.W) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const float v = acc[n][j];
+                            o[(size_t)gx * g.Cout + n * 16] = v;
+                            s1[n] += (double)v; s2[n] += (double)v * (double)v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            double u = s1[n], v = s2[n];
+            u += __shfl_xor(u, 16); v += __shfl_xor(v, 16);
+            u += __shfl_xor(u, 32); v += __shfl_xor(v, 32);
+            if (lq == 0) { red[((wave * NT + n) * 16 + lx) * 2] = u; red[((wave * NT + n) * 16 + lx) * 2 + 1] = v; }
+        }
+        __syncthreads();
+        if (tid < NT * 16) {
+            double u = 0.0, v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { u += red[(w * NT * 16 + tid) * 2]; v += red[(w * NT * 16 + tid) * 2 + 1]; }
+            a.stats[((size_t)blockIdx.x * g.Cout + tid) * 2] = u;
+            a.stats[((size_t)blockIdx.x * g.Cout + tid) * 2 + 1] = v;
+        }
+    }
+}
+}  // namespace
+
+bool conv_first_f32_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
+    return dtype == 0 && nsrc == 1 && g.Cin == 1 && g.ks == 3 && g.stride == 1 && (g.Cout == 16 || g.Cout == 32) && !src[0].scale &&
+           src[0].act == 0 && src[0].C == 1;
+}
+int conv_first_f32_mfma_blocks(const ConvGeom& g) {
+    const int tiles = ((g.W + 15) / 16) * ((g.H + 7) / 8) * ((g.D + 3) / 4);
+    return tiles < 1024 ? tiles : 1024;
+}
+// returns the number of statistics rows written (one per block) when stats_partial is given
+int launch_conv_first_f32_mfma(const ConvGeom& g, const SrcDesc* src, const float* w, const float* bias, float* out, double* stats_partial,
+                               hipStream_t s) {
+    ConvFirstF32Args a;
+    a.g = g; a.x = (const float*)src[0].ptr; a.w = w; a.bias = bias; a.out = out; a.stats = stats_partial;
+    a.tiles_x = (g.W + 15) / 16; a.tiles_y = (g.H + 7) / 8; a.tiles_z = (g.D + 3) / 4;
+    const int nb = conv_first_f32_mfma_blocks(g);
+    if (g.Cout == 16) k_conv_first_f32_mfma<1><<<nb, 256, 0, s>>>(a);
+    else k_conv_first_f32_mfma<2><<<nb, 256, 0, s>>>(a);
+    return nb;
 }
 
 // ================================================================================================================
