@@ -316,7 +316,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event profile (roofline / conv_mfma_frac)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the single-kernel micro-benchmarks (roofline_kernels)")
-    ap.add_argument("--batch", type=int, default=8, help="the reference's step shape (train.cpp:604-606: batch_size micro-steps per update, "
+    ap.add_argument("--batch", type=int, default=None, help="(default: 8 on one GPU, 0 = off on several) the reference's step shape (train.cpp:604-606: batch_size micro-steps per update, "
                     "train.hpp:12 default 32; SURVEY 8(d) config 3 asks for 8): B micro-steps per GPU per optimizer step, timed AFTER the "
                     "headline and reported as `batch<B>` inside the same line; 0 = skip")
     # BASELINE.json configs[4] (not the headline line): --size 256 --in-channels 2 --augment --no-cpu-baseline
@@ -331,6 +331,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.batch is None:     # SURVEY 8(d) config 3 asks for batch_size 8 on ONE GPU; the scaling runs time the headline step only
+        a.batch = 8 if world == 1 else 0
     if a.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
