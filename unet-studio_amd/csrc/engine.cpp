@@ -116,6 +116,7 @@ struct unet_plan {
     int pack_split_op = 0;
     int64_t pack_split_blocks = 0;
     size_t head_off = 0;                     // scratch of the fused head backward (stays on the main stream)
+    std::vector<size_t> head_op_off;         // per op: a head's own slab region (its reduce runs on the side stream, later) or SIZE_MAX
 
     ~unet_plan() {
         if (segs_dev) (void)hipFree(segs_dev);
@@ -268,6 +269,13 @@ struct unet_plan {
         }
         wgrad_off = take(wmax ? wmax : 256);
         head_off = take(hmax ? hmax : 256);
+        head_op_off.assign(g.ops.size(), SIZE_MAX);
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV || op.out_level < 0 || impl != UNET_IMPL_AUTO) continue;
+            ConvGeom cg = op_geom_of(op);
+            if (head_supported(cg, op.nsrc)) head_op_off[i] = take(head_bwd_scratch_bytes(cg));
+        }
         // every matrix-core weight gradient keeps a slab region of its own until the batched reduce of the backward (part)
         wz_off.assign(g.ops.size(), SIZE_MAX);
         for (size_t i = 0; i < g.ops.size(); ++i) {
@@ -709,8 +717,16 @@ struct Exec {
                     // fused head backward: dL/dW, dL/db and dL/d(source view) in one pass over (source, dL/dresults[level])
                     DstGrad dgh = dst_of(op.src[0]);
                     ProfScope ph(dry ? -2 : i, UNET_PROF_OTHER, s);
-                    if (!dry) launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
-                                    gparams[op.weight], gparams[op.bias], ws + p.head_off, s);
+                    if (!dry) {
+                        // the slab sum that finishes the head's dW / db feeds nothing on the caller's chain: on the side stream (a slab region
+                        // per head, so the next level's head does not overwrite rows that have not been summed yet)
+                        static const bool head_side = getenv("UNET_HEAD_REDUCE_MAIN") == nullptr;
+                        const bool defer = head_side && sb != s && p.head_op_off[i] != SIZE_MAX;
+                        char* hs = ws + (defer ? p.head_op_off[i] : p.head_off);
+                        launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
+                                        gparams[op.weight], gparams[op.bias], hs, s, defer);
+                        if (defer) { fork(); launch_head_bwd_reduce(geom(op), gparams[op.weight], gparams[op.bias], hs, sb); }
+                    }
                     if (dgh.ptr) mark(op);
                     continue;
                 }

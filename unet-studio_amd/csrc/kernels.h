@@ -190,8 +190,10 @@ bool head_supported(const ConvGeom& g, int nsrc);
 size_t head_bwd_scratch_bytes(const ConvGeom& g);
 void launch_head_fwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* w, const float* bias, void* y, float* out_ncdhw,
                      hipStream_t s);
+// defer_reduce: only the slab is written (scratch must stay untouched until launch_head_bwd_reduce has run on a stream ordered after `s`)
 void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* dy_ncdhw, const void* dy_cl, const float* w,
-                     DstGrad dst, float* dw, float* db, void* scratch, hipStream_t s);
+                     DstGrad dst, float* dw, float* db, void* scratch, hipStream_t s, bool defer_reduce = false);
+void launch_head_bwd_reduce(const ConvGeom& g, float* dw, float* db, const void* scratch, hipStream_t s);
 // wgrad (+ bias grad) of the first conv (Cin = 1, 3x3x3 stride 1, Cout 16 or 32, plain bf16 input) on the matrix cores
 bool conv_first_wgrad_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g);

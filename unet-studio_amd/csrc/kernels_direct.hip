@@ -1027,8 +1027,10 @@ void launch_head_fwd(int dtype, const ConvGeom& g, const SrcDesc& src, const flo
     if (nb > 2048) nb = 2048;
     UNET_DISPATCH(dtype, (head_launch<T>(false, CO, (int)nb, (size_t)CO * g.Cin * 4, a, s)));
 }
+// reduce_stream (optional): the slab sum that finishes dW / db runs there instead of on `s` -- it feeds nothing on the caller's
+// chain; the CALLER orders reduce_stream after this launch (an event) and keeps `scratch` untouched until the reduce has run
 void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const float* dy_ncdhw, const void* dy_cl, const float* w,
-                     DstGrad dst, float* dw, float* db, void* scratch, hipStream_t s) {
+                     DstGrad dst, float* dw, float* db, void* scratch, hipStream_t s, bool defer_reduce) {
     HeadArgs a = {};
     a.src = src; a.w = w; a.Cin = g.Cin; a.Cout = g.Cout; a.lc = ilog2_exact(g.Cin / 16);
     a.S = (int64_t)g.D * g.H * g.W; a.dy_planes = dy_ncdhw; a.dy_cl = dy_cl; a.dst = dst;
@@ -1037,7 +1039,13 @@ void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const flo
     const int nb = wgrad_reg_blocks((a.S << a.lc) * 4);   // one (voxel, chunk) item per thread until 512 blocks are reached
     const size_t l0 = (size_t)CO * g.Cin * 4, l1 = small_wgrad_lds_bytes(CO * 17, 1 << a.lc);
     UNET_DISPATCH(dtype, (head_launch<T>(true, CO, nb, l0 > l1 ? l0 : l1, a, s)));
-    if (dw) slab_reduce2(a.slab, nb, (int64_t)g.Cin * g.Cout + g.Cout, dw, (int64_t)g.Cin * g.Cout, db, s);
+    if (dw && !defer_reduce) slab_reduce2(a.slab, nb, (int64_t)g.Cin * g.Cout + g.Cout, dw, (int64_t)g.Cin * g.Cout, db, s);
+}
+// the deferred half of launch_head_bwd(..., defer_reduce = true): dw / db += the slab rows, on `s`
+void launch_head_bwd_reduce(const ConvGeom& g, float* dw, float* db, const void* scratch, hipStream_t s) {
+    const int lc = ilog2_exact(g.Cin / 16);
+    const int nb = wgrad_reg_blocks((((int64_t)g.D * g.H * g.W) << lc) * 4);
+    slab_reduce2((const float*)scratch, nb, (int64_t)g.Cin * g.Cout + g.Cout, dw, (int64_t)g.Cin * g.Cout, db, s);
 }
 
 }  // namespace unet
