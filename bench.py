@@ -341,6 +341,8 @@ def main():
         raise SystemExit("bench.py --gpus %d: %d devices needed, %d visible" % (a.gpus, a.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
+    if os.environ.get("UNET_BENCH_STREAM"):     # experiment: the whole run on a stream of torch's pool instead of the null stream
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

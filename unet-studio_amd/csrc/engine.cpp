@@ -136,8 +136,34 @@ struct unet_plan {
         cg.ks = op.ks; cg.stride = op.stride;
         return cg;
     }
+    // Which weight-gradient launches are "polite" (ConvGeom::polite; one 4-wave block per CU).  The backward walks the ops from the last
+    // to the first: the decoder's top levels (their gradients are HELD, see backward()), then the small levels, then the encoder's top
+    // levels.  Everything that runs on the side stream while the caller's stream still has latency-bound small kernels ahead is polite;
+    // the encoder's top levels are the tail of the step -- nothing is left to run beside them, they get the whole chip.
+    // UNET_SIDE_POLITE=0: none; UNET_POLITE_ALL=1: the tail as well.
+    std::vector<int> side_polite;
+    void choose_polite() {
+        side_polite.assign(g.ops.size(), 0);
+        const char* e = getenv("UNET_SIDE_POLITE");
+        if (e && e[0] == '0' && e[1] == 0) return;
+        static const bool all = getenv("UNET_POLITE_ALL") != nullptr;
+        const int64_t deep = (int64_t)32 * 32 * 32;
+        int last_deep = -1;
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
+            if (g.tensors[op.dst].voxels() <= deep) last_deep = (int)i;
+        }
+        if (last_deep < 0) return;
+        for (size_t i = 0; i < g.ops.size(); ++i) {
+            const Op& op = g.ops[i];
+            if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
+            side_polite[i] = (all || g.tensors[op.dst].voxels() <= deep || (int)i > last_deep) ? 1 : 0;
+        }
+    }
 
     void layout() {
+        choose_polite();
         size_t off = 0;
         auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
         t_off.assign(g.tensors.size(), SIZE_MAX);
@@ -225,7 +251,7 @@ struct unet_plan {
             for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
             if (mfma_wgrad_supported(dtype, cg, sd, op.nsrc)) {
                 wgrad_mfma[i] = 1;
-                size_t b = mfma_wgrad_scratch_bytes(cg);
+                size_t b = mfma_wgrad_scratch_bytes(cg, side_polite[i]);
                 if (b > wmax) wmax = b;
             }
         }
@@ -285,7 +311,7 @@ struct unet_plan {
             SrcDesc sd[2];
             for (int k = 0; k < op.nsrc; ++k) sd[k].C = g.tensors[op.src[k]].C;
             if (op.kind == OP_CONV && conv_first_wgrad_mfma_supported(dtype, cg, sd, op.nsrc)) wz_off[i] = take(conv_first_wgrad_mfma_scratch_bytes(cg));
-            else if (op.kind == OP_CONV && wgrad_mfma[i]) { if (!mfma_conv_wgrad_direct(cg)) wz_off[i] = take(mfma_wgrad_scratch_bytes(cg)); }
+            else if (op.kind == OP_CONV && wgrad_mfma[i]) { if (!mfma_conv_wgrad_direct(cg)) wz_off[i] = take(mfma_wgrad_scratch_bytes(cg, side_polite[i])); }
             else if (op.kind == OP_CONVT && wgrad_mfma[i]) { if (!mfma_convt_wgrad_direct(cg)) wz_off[i] = take(mfma_convt_wgrad_scratch_bytes(cg)); }
         }
         ws_bytes = off;
@@ -314,7 +340,7 @@ struct unet_plan {
                 j.bias_off = op.bias >= 0 ? j.slab_off + (long long)j.nsplit * j.n : -1;
                 j.db_off = op.bias >= 0 ? p_off[op.bias] : -1;
             } else {
-                j.nsplit = (op.cin == 1) ? conv_first_wgrad_splits(cg) : mfma_conv_wgrad_splits(cg);
+                j.nsplit = (op.cin == 1) ? conv_first_wgrad_splits(cg) : mfma_conv_wgrad_splits(cg, side_polite[i]);
                 j.n = (long long)27 * op.cin * op.cout;
                 j.bias_off = op.bias >= 0 ? j.slab_off + (long long)j.nsplit * j.n : -1;
                 j.db_off = op.bias >= 0 ? p_off[op.bias] : -1;
@@ -414,8 +440,11 @@ struct Exec {
                     if (p.pack_split_op > 0 && p.pack_split_blocks > 0 && !one_pack) {
                         launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_split_blocks, p.side);
                         HIP_OK(hipEventRecord(p.ev_join, p.side));
+                        // the deep levels' packs (most of the bytes) are not needed for the next ~0.3 ms: a bounded grid, so that the first
+                        // full-resolution convs keep the CUs (UNET_PACK_GRID; 0 = a block per unit)
+                        static const int pack_grid = getenv("UNET_PACK_GRID") ? atoi(getenv("UNET_PACK_GRID")) : 0;
                         launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks - p.pack_split_blocks, p.side,
-                                                 p.pack_split_blocks);
+                                                 p.pack_split_blocks, pack_grid);
                         HIP_OK(hipEventRecord(p.ev_pack, p.side));
                         pack2_pending = true;
                     } else {
@@ -658,7 +687,7 @@ struct Exec {
                 } else if (p.wgrad_mfma[i]) {
                     const bool defer = gflat && p.wz_job_of_op[i] >= 0;   // slab only: summed by the batched reduce below
                     launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias],
-                                           ws + (p.wz_off[i] != SIZE_MAX ? p.wz_off[i] : p.wgrad_off), sb, defer);
+                                           ws + (p.wz_off[i] != SIZE_MAX ? p.wz_off[i] : p.wgrad_off), sb, defer, p.side_polite[i]);
                     if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
                 }
                 else if (p.impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
@@ -669,7 +698,7 @@ struct Exec {
                     launch_conv_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
             } else if (p.wgrad_mfma[i]) {
                 const bool defer = gflat && p.wz_job_of_op[i] >= 0;
-                launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer, gparams[op.bias]);
+                launch_mfma_convt_wgrad(cg, sd, gptr(t), gparams[op.weight], ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer, gparams[op.bias], p.side_polite[i]);
                 if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
             } else {
                 launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
@@ -911,7 +940,26 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
             DeviceGuard dg(device);
             int pr_least = 0, pr_greatest = 0;   // the side stream yields to the caller's (critical-path) stream
             (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-            HIP_OK(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, pr_least));
+            // UNET_SIDE_CUS=<n>: the side stream may use n CUs of every XCD (a CU mask; bit i of the mask = CU i / 8 of XCD i % 8 on this
+            // part -- profiles/tools/cu_mask_probe.hip; a mask that leaves an XCD without CUs is ignored by the driver), so that the
+            // caller's stream always finds CUs whose registers and LDS are not held by long weight-gradient blocks.  0 = all CUs.
+            static const int side_cus = getenv("UNET_SIDE_CUS") ? atoi(getenv("UNET_SIDE_CUS")) : 0;
+            static const int side_cu0 = getenv("UNET_SIDE_CU_FIRST") ? atoi(getenv("UNET_SIDE_CU_FIRST")) : 0;
+            hipDeviceProp_t prop;
+            bool masked = false;
+            if (side_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount % 8 == 0) {
+                const int per_xcd = prop.multiProcessorCount / 8;
+                if (side_cus < per_xcd) {
+                    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+                    for (int c = 0; c < side_cus; ++c) {
+                        const int cu = (side_cu0 + c) % per_xcd;
+                        for (int x = 0; x < 8; ++x) { const int bit = cu * 8 + x; mask[bit / 32] |= 1u << (bit % 32); }
+                    }
+                    masked = hipExtStreamCreateWithCUMask(&p->side, (uint32_t)mask.size(), mask.data()) == hipSuccess;
+                    if (!masked) (void)hipGetLastError();
+                }
+            }
+            if (!masked) HIP_OK(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, pr_least));
             // the plan's events only order its two streams on ONE device: no host ever waits on them, so the system-scope fence a
             // default event performs when it is recorded (cache write-back for host visibility) is not needed (UNET_EVENT_SYSFENCE=1 keeps it)
             const unsigned evf = hipEventDisableTiming | ((getenv("UNET_EVENT_SYSFENCE") && getenv("UNET_EVENT_SYSFENCE")[0] == '1') ? 0u : hipEventDisableSystemFence);

@@ -140,9 +140,10 @@ void launch_sgd(float* p, float* g, float* m, int64_t n, const SgdSeg* segs_dev,
 struct PackJob { int64_t src_off, dst_off, total, blk0; int Ci, Co, CK, T, mode, A, B, pad; };
 int mfma_conv_pack_jobs(const ConvGeom& g, bool want_dgrad, PackJob* out2);
 int mfma_convt_pack_jobs(const ConvGeom& g, PackJob* out2);
-// one launch serves the pack units [blk_base, blk_base + nblocks) of the table (njobs = the whole table)
+// one launch serves the pack units [blk_base, blk_base + nblocks) of the table (njobs = the whole table); max_grid > 0 bounds the
+// number of blocks (a block then walks several units)
 void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s,
-                              int64_t blk_base = 0);
+                              int64_t blk_base = 0, int max_grid = 0);
 bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_conv_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
@@ -161,9 +162,10 @@ int mfma_conv_blocks(const ConvGeom& g);
 // sliding-window wgrad of the 3x3x3 stride-1 convs (kernels_mfma_wgrad_z.hip): kernel only, returns the number of slab rows
 // written at `scratch` ([rows][Cout][Cin][27], then [rows][Cout] bias partials when want_bias); 0 = shape not covered
 bool mfma_wgrad_z_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
-size_t mfma_wgrad_z_scratch_bytes(const ConvGeom& g);
-int mfma_wgrad_z_splits(const ConvGeom& g);
-int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, bool want_bias, void* scratch, hipStream_t s);
+size_t mfma_wgrad_z_scratch_bytes(const ConvGeom& g, int polite = 0);
+int mfma_wgrad_z_splits(const ConvGeom& g, int polite = 0);
+int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, bool want_bias, void* scratch, hipStream_t s,
+                        int polite = 0);
 // dw[i] += sum over rows of slab[row][i] (n % 4 == 0), db[c] += sum of bias_slab[row][c]; fixed order, no atomics
 void wgrad_reduce(const float* slab, const float* bias_slab, int nsplit, int64_t n, int Cb, float* dw, float* db, hipStream_t s);
 // one launch for many layers' slabs: offsets in floats from the workspace base (slab, bias partials; bias_off < 0: none) and
@@ -173,16 +175,19 @@ int wgrad_reduce_job_blocks(WgradReduceJob& j, int blk0);
 void launch_wgrad_reduce_batched(const WgradReduceJob* jobs_dev, int job0, int njobs, int blk_base, int nblocks, const void* ws, float* gflat,
                                  hipStream_t s);
 bool mfma_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
-size_t mfma_wgrad_scratch_bytes(const ConvGeom& g);
+// polite = 1 (weight-gradient launches only): the layer's gradient runs on the side stream beside the caller's stream's latency-bound small
+// levels -- one 4-wave block per CU (one wave per SIMD), so that the caller's kernels always find registers and LDS.  The slab row count
+// depends on it: the same value must be given to *_scratch_bytes, *_splits and the launch (engine.cpp: Plan::side_polite).
+size_t mfma_wgrad_scratch_bytes(const ConvGeom& g, int polite = 0);
 // defer_reduce: only the slab ([rows][n] + [rows][Cout] bias partials at `scratch`) is written; rows = *_wgrad_splits(g)
-int mfma_conv_wgrad_splits(const ConvGeom& g);
+int mfma_conv_wgrad_splits(const ConvGeom& g, int polite = 0);
 int mfma_convt_wgrad_splits(const ConvGeom& g);
 // small volumes: the launch ADDS its result into dw / db itself (output-stationary blocks; no slab, defer_reduce is ignored)
 bool mfma_conv_wgrad_direct(const ConvGeom& g);
 bool mfma_convt_wgrad_direct(const ConvGeom& g);
 int conv_first_wgrad_splits(const ConvGeom& g);
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
-                            hipStream_t s, bool defer_reduce = false);
+                            hipStream_t s, bool defer_reduce = false, int polite = 0);
 // wgrad of layers with <= 1024 weights (Cin = 1 first conv, 6-channel heads): row-staged, HBM-bound
 // 1x1x1 heads (Cout <= 8, Cin = 16 * 2^k <= 256, one plain or viewed source): forward writes results[level] (fp32 NCDHW) and/or
 // the channels-last tensor; backward = dL/dW (+=), dL/db (+=) and dL/d(source view) in one pass, dy as fp32 NCDHW or channels-last
@@ -208,7 +213,7 @@ void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, i
 bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g);
 void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s,
-                             bool defer_reduce = false, float* db = nullptr);
+                             bool defer_reduce = false, float* db = nullptr, int polite = 0);
 // vectorised per-block column sums partial[blk][C] of a bf16 [S][C] tensor; returns #blocks (0: not applicable)
 int launch_colsum_partial8(int dtype, const void* x, int C, int64_t S, float* partial, hipStream_t s);
 size_t bias_grad_scratch_bytes(int C, int64_t S);

@@ -119,23 +119,31 @@ __global__ void __launch_bounds__(256) k_mfma_pack(const float* __restrict__ w, 
     __shared__ __bf16 lds[PACK_LDS_ELEMS];
     pack_unit(w, out, blockIdx.x, Ci, Co, CK, T, mode, A, B, lds);
 }
-// every filter pack of a plan in ONE launch: block -> (job, unit) by binary search over the jobs' first block index
+// every filter pack of a plan in ONE launch: block -> (job, unit) by binary search over the jobs' first block index.  The launch serves
+// the pack units [blk_base, blk_base + nunits) of the job table; with fewer blocks than units a block walks units blockIdx.x,
+// blockIdx.x + gridDim.x, ... (the deep levels' packs run on the side stream beside the forward's first convs and are not needed
+// before the caller's stream reaches those levels: a bounded grid leaves the CUs' LDS and wave slots to the convs).
 __global__ void __launch_bounds__(256) k_mfma_pack_batched(const float* __restrict__ params_base, char* __restrict__ ws,
-                                                           const PackJob* __restrict__ jobs, int njobs, int64_t blk_base) {
+                                                           const PackJob* __restrict__ jobs, int njobs, int64_t blk_base, int64_t nunits) {
     __shared__ __bf16 lds[PACK_LDS_ELEMS];
-    const int64_t blk = blk_base + blockIdx.x;      // a launch serves the pack units [blk_base, blk_base + gridDim.x) of the job table
-    int lo = 0, hi = njobs - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+    for (int64_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int64_t blk = blk_base + u;
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].blk0 <= blk) lo = mid; else hi = mid - 1;
+        }
+        const PackJob jb = jobs[lo];
+        pack_unit(params_base + jb.src_off, (__bf16*)(ws + jb.dst_off), (int)(blk - jb.blk0), jb.Ci, jb.Co, jb.CK, jb.T,
+                  jb.mode, jb.A, jb.B, lds);
+        __syncthreads();                              // the unit's fragments are read from LDS before the next unit overwrites it
     }
-    const PackJob jb = jobs[lo];
-    pack_unit(params_base + jb.src_off, (__bf16*)(ws + jb.dst_off), (int)(blk - jb.blk0), jb.Ci, jb.Co, jb.CK, jb.T,
-              jb.mode, jb.A, jb.B, lds);
 }
 void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s,
-                              int64_t blk_base) {
-    if (njobs > 0 && nblocks > 0) k_mfma_pack_batched<<<(unsigned)nblocks, 256, 0, s>>>(params_base, (char*)ws, jobs_dev, njobs, blk_base);
+                              int64_t blk_base, int max_grid) {
+    if (njobs <= 0 || nblocks <= 0) return;
+    const int64_t grid = (max_grid > 0 && nblocks > max_grid) ? max_grid : nblocks;
+    k_mfma_pack_batched<<<(unsigned)grid, 256, 0, s>>>(params_base, (char*)ws, jobs_dev, njobs, blk_base, nblocks);
 }
 
 static inline int pick_ck(int Ci, bool allow32) { return (allow32 && Ci % 32 == 0) ? 32 : 16; }

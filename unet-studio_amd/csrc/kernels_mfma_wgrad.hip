@@ -696,7 +696,7 @@ bool mfma_convt_wgrad_supported(int dtype, const ConvGeom& g, const SrcDesc* src
 }
 
 // kind 0: conv stride 1, 1: conv stride 2, 2: conv_trans.  Ca/Cb and the tile-side grid width decide the configuration.
-struct WgradCfg { int bz, by, bx, pi, pj, nsplit, gy, direct; };
+struct WgradCfg { int bz, by, bx, pi, pj, nsplit, gy, direct, polite = 0; };
 // Small volumes (tile side 4^3 or 8^3 voxels: the 8^3 / 4^3 levels of the default architecture, K = 64..512 voxels, gradients of
 // 2..14 MB): output-stationary.  One block per (ca, cb) pair owns the pair's T tap tiles for the WHOLE volume (4 waves split the
 // taps), walks the volume's tiles and adds its result straight into the gradient: >= 128 blocks, no slab write, no reduce read.
@@ -742,8 +742,8 @@ static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
     c.nsplit = tiles < want ? tiles : want;
     return c;
 }
-size_t mfma_wgrad_scratch_bytes(const ConvGeom& g) {
-    if (size_t z = mfma_wgrad_z_scratch_bytes(g)) return z;
+size_t mfma_wgrad_scratch_bytes(const ConvGeom& g, int polite) {
+    if (size_t z = mfma_wgrad_z_scratch_bytes(g, polite)) return z;
     WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
     return ((size_t)c.nsplit * 27 * g.Cin * g.Cout + (size_t)c.nsplit * g.Cout) * 4 + 256;
 }
@@ -764,10 +764,11 @@ static void launch_wgrad_cfg(const MfmaWgradArgs& a0, const WgradCfg& c, hipStre
     constexpr size_t lds = lds0 > stg_lds ? lds0 : stg_lds;
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static std::atomic<uint64_t> attr_done{0};
-    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, (int)lds);
+    const int lds_launch = polite_lds((int)lds, c.polite);
+    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, lds_launch);
     dim3 grid((unsigned)c.nsplit, (unsigned)c.gy);
     a.direct = c.direct;
-    k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ><<<grid, 256, lds, s>>>(a);
+    k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ><<<grid, 256, lds_launch, s>>>(a);
 }
 template <int S, int KD, int PAD, int BZ, int BY, int BX>
 static void launch_wgrad_p(const MfmaWgradArgs& a, const WgradCfg& c, hipStream_t s) {
@@ -784,8 +785,8 @@ static void launch_wgrad_p(const MfmaWgradArgs& a, const WgradCfg& c, hipStream_
 }
 
 // rows of the slab a launch leaves at `scratch` ([rows][27*Cin*Cout], then [rows][Cout] bias partials): plan-time constant
-int mfma_conv_wgrad_splits(const ConvGeom& g) {
-    if (int z = mfma_wgrad_z_splits(g)) return z;
+int mfma_conv_wgrad_splits(const ConvGeom& g, int polite) {
+    if (int z = mfma_wgrad_z_splits(g, polite)) return z;
     return wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo).nsplit;
 }
 int mfma_convt_wgrad_splits(const ConvGeom& g) { return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).nsplit; }
@@ -797,15 +798,16 @@ bool mfma_conv_wgrad_direct(const ConvGeom& g) {
 bool mfma_convt_wgrad_direct(const ConvGeom& g) { return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).direct != 0; }
 // defer_reduce: leave the slab for the caller's batched reduce (launch_wgrad_reduce_batched) instead of summing it here
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
-                            hipStream_t s, bool defer_reduce) {
+                            hipStream_t s, bool defer_reduce, int polite) {
     if (mfma_wgrad_z_supported(1, g, src, nsrc)) {   // sliding-window kernel (kernels_mfma_wgrad_z.hip): stride 1, W >= 24
-        const int ns = launch_mfma_wgrad_z(g, src, nsrc, dy, db != nullptr, scratch, s);
+        const int ns = launch_mfma_wgrad_z(g, src, nsrc, dy, db != nullptr, scratch, s, polite);
         const float* slab = (const float*)scratch;
         if (!defer_reduce)
             wgrad_reduce(slab, db ? slab + (size_t)ns * 27 * g.Cin * g.Cout : nullptr, ns, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
         return;
     }
     WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
+    c.polite = polite;
     MfmaWgradArgs a;
     a.g = g; a.nasrc = nsrc; a.asrc[0] = src[0]; if (nsrc > 1) a.asrc[1] = src[1];
     a.bsrc = SrcDesc(); a.bsrc.ptr = dy; a.bsrc.C = g.Cout;
@@ -836,8 +838,9 @@ void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, con
 // conv_trans wgrad (g = forward geometry of the conv_trans: D,H,W coarse input, Do,Ho,Wo fine output).
 // halo side A = dy (fine, Cout channels), tile side B = transformed input (coarse, Cin channels): D_t[co][ci].
 void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s, bool defer_reduce,
-                             float* db) {
+                             float* db, int polite) {
     WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
+    c.polite = polite;
     MfmaWgradArgs a;
     a.bias_from_a = 1;
     a.g.Cin = g.Cout; a.g.Cout = g.Cin; a.g.D = g.Do; a.g.H = g.Ho; a.g.W = g.Wo; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W;

@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
 // ---- configuration / launch ----
 struct WgradZCfg { int bx, wk, pa, pb, by, cols_x, cols_y, nseg, zlen, gx, gy; };
 
-static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c) {
+static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c, int polite = 0) {
     static const bool off = getenv("UNET_NO_WGRAD_Z") != nullptr;
     if (off || g.ks != 3 || g.stride != 1 || g.Cin % 16 || g.Cout % 16) return false;
     if (g.W < 24 || g.D < 4) return false;                 // narrower volumes: k_mfma_wgrad
@@ -394,14 +394,19 @@ static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c) {
     // at 32^3 a 2x2-pair block leaves 128 blocks for the chip (4 footprint columns x 8 segments x 4 pair groups); single pairs give 512
     // (step 3.22 -> 3.19 ms; at 64^3 no difference).  UNET_WZ_P11 = voxel count at or below which single pairs are used.
     static const int p11_vox = getenv("UNET_WZ_P11") ? atoi(getenv("UNET_WZ_P11")) : 32768;
-    if (p11_vox > 0 && (int64_t)g.D * g.H * g.W <= (int64_t)p11_vox) { c.pa = 1; c.pb = 1; c.wk = 4; }
+    if ((p11_vox > 0 && (int64_t)g.D * g.H * g.W <= (int64_t)p11_vox) || polite) { c.pa = 1; c.pb = 1; c.wk = 4; }   // polite: 4-wave blocks
     c.by = 2 * c.wk;
     c.cols_x = (g.W + c.bx - 1) / c.bx; c.cols_y = (g.H + c.by - 1) / c.by;
     c.gy = (cat / c.pa) * (cbt / c.pb);
     const int cols = c.cols_x * c.cols_y;
     const int nwaves = c.wk * c.pa * c.pb;
     static const int want_env = getenv("UNET_WZ_BLOCKS") ? atoi(getenv("UNET_WZ_BLOCKS")) : 0;   // experiment knob: blocks per launch
-    int want = (want_env > 0 ? want_env : (nwaves == 4 ? 512 : 256)) / c.gy;           // ~8 waves per CU in total
+    static const int want8_env = getenv("UNET_WZ_BLOCKS8") ? atoi(getenv("UNET_WZ_BLOCKS8")) : 0;   // the same for the 8-wave pair blocks
+    static const int wantp_env = getenv("UNET_WZ_BLOCKSP") ? atoi(getenv("UNET_WZ_BLOCKSP")) : 0;   // ... and for polite launches
+    // ~8 waves per CU in total; a polite launch is resident in one round at one block per CU
+    int want = nwaves == 4 ? (polite ? (wantp_env > 0 ? wantp_env : 256) : (want_env > 0 ? want_env : 512))
+                           : (want8_env > 0 ? want8_env : (want_env > 0 ? want_env : 256));
+    want /= c.gy;
     if (want < 1) want = 1;
     int nseg = (want + cols - 1) / cols;
     if (nseg < 1) nseg = 1;
@@ -419,23 +424,24 @@ bool mfma_wgrad_z_supported(int dtype, const ConvGeom& g, const SrcDesc* src, in
         if (src[s].C % 16 || src[s].scale || src[s].act) return false;
     return true;
 }
-int mfma_wgrad_z_splits(const ConvGeom& g) {
+int mfma_wgrad_z_splits(const ConvGeom& g, int polite) {
     WgradZCfg c;
-    return wgrad_z_cfg(g, c) ? c.gx : 0;
+    return wgrad_z_cfg(g, c, polite) ? c.gx : 0;
 }
-size_t mfma_wgrad_z_scratch_bytes(const ConvGeom& g) {
+size_t mfma_wgrad_z_scratch_bytes(const ConvGeom& g, int polite) {
     WgradZCfg c;
-    if (!wgrad_z_cfg(g, c)) return 0;
+    if (!wgrad_z_cfg(g, c, polite)) return 0;
     return ((size_t)c.gx * 27 * g.Cin * g.Cout + (size_t)c.gx * g.Cout) * 4 + 256;
 }
 
 template <int BX, int WK, int PA, int PB>
-static void launch_wz(const WgradZArgs& a, const WgradZCfg& c, hipStream_t s) {
+static void launch_wz(const WgradZArgs& a, const WgradZCfg& c, hipStream_t s, int polite) {
     constexpr int RPK = 32 / BX, BY = 2 * WK * RPK, HY = BY + 2, HX = BX + 2;
     constexpr int lds = 2 * (PA * HY * HX * 32 + PB * BY * BX * 32);
     static_assert(lds <= 80 * 1024, "LDS budget");
     static std::atomic<uint64_t> attr_done{0};
-    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, lds);
+    const int lds_launch = (WK * PA * PB == 4) ? polite_lds(lds, polite) : lds;
+    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, lds_launch);
     static const bool dbg = getenv("UNET_WZ_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
@@ -443,14 +449,15 @@ static void launch_wz(const WgradZArgs& a, const WgradZCfg& c, hipStream_t s) {
         fprintf(stderr, "k_mfma_wgrad_z<%d,%d,%d,%d>: grid %d x %d, %d threads, %d B LDS, zlen %d, occupancy API: %d blocks/CU\n", BX, WK, PA, PB,
                 c.gx, c.gy, 64 * WK * PA * PB, lds, c.zlen, nb);
     }
-    k_mfma_wgrad_z<BX, WK, PA, PB><<<dim3((unsigned)c.gx, (unsigned)c.gy), 64 * WK * PA * PB, lds, s>>>(a);
+    k_mfma_wgrad_z<BX, WK, PA, PB><<<dim3((unsigned)c.gx, (unsigned)c.gy), 64 * WK * PA * PB, lds_launch, s>>>(a);
 }
 
 // Launches the kernel only: slab [gx][Cout][Cin][27] (+ bias_slab [gx][Cout] when want_bias) at `scratch`; returns the number of
 // slab rows (0: shape not covered).  The caller sums the rows (wgrad_reduce / the plan's batched reduce).
-int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, bool want_bias, void* scratch, hipStream_t s) {
+int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, bool want_bias, void* scratch, hipStream_t s,
+                        int polite) {
     WgradZCfg c;
-    if (!wgrad_z_cfg(g, c)) return 0;
+    if (!wgrad_z_cfg(g, c, polite)) return 0;
     WgradZArgs a;
     a.g = g; a.nasrc = nsrc; a.asrc[0] = src[0]; if (nsrc > 1) a.asrc[1] = src[1];
     a.dy = dy;
@@ -459,10 +466,10 @@ int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const v
     a.cols_x = c.cols_x; a.cols_y = c.cols_y; a.nseg = c.nseg; a.zlen = c.zlen;
     static const bool noslab = getenv("UNET_WZ_NOSLAB") != nullptr;   // timing experiment only (results are wrong): skip the slab stores
     if (noslab) a.nseg = -c.nseg;
-    if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s);
-    else if (c.pa == 2) launch_wz<32, 4, 2, 1>(a, c, s);
-    else if (c.pb == 2) launch_wz<32, 4, 1, 2>(a, c, s);
-    else launch_wz<32, 4, 1, 1>(a, c, s);
+    if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s, polite);
+    else if (c.pa == 2) launch_wz<32, 4, 2, 1>(a, c, s, polite);
+    else if (c.pb == 2) launch_wz<32, 4, 1, 2>(a, c, s, polite);
+    else launch_wz<32, 4, 1, 1>(a, c, s, polite);
     return c.gx;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 
 #include "device_util.h"
 
@@ -17,6 +18,16 @@ inline void set_max_lds_once(std::atomic<uint64_t>& done, const void* fn, int by
     if (done.load(std::memory_order_acquire) & bit) return;
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done.fetch_or(bit, std::memory_order_release);
+}
+
+// A "polite" weight-gradient launch (ConvGeom::polite) asks for more than half of a CU's LDS, so that a CU holds ONE of its 4-wave
+// blocks: one wave per SIMD, >= 256 VGPRs per SIMD and ~77 KB of LDS left for the kernels of the caller's stream.  Measured (time line of
+// a step, profiles/r10a_stretch.txt): at two blocks per CU a 240-VGPR weight-gradient kernel fills every SIMD's register file, and a
+// 5-us norm kernel of the caller's stream that became ready beside it waited 64 us for the first block to leave.
+// UNET_SIDE_POLITE=<bytes> overrides the request (0 = off).
+inline int polite_lds(int lds, int polite) {
+    static const int want = getenv("UNET_SIDE_POLITE") ? atoi(getenv("UNET_SIDE_POLITE")) : 83000;
+    return (polite && want > lds) ? want : lds;
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -61,6 +61,8 @@ class Trainer:
         # measured on MI355X at 128^3 bf16, batch 8: 2.99 ms per sample sequentially, 3.76 ms with two in flight -- kernels of two
         # samples that share the chip thrash each other's L2 patches and LDS occupancy)
         self.in_flight = max(1, int(os.environ.get("UNET_MICRO_IN_FLIGHT", "1")))
+        # the engine writes the first micro-step's {total, ce, dice, mse} straight into the step's statistics (no zeroing launch, no add)
+        self.stats_direct = hasattr(model, "_run_forward_loss") and os.environ.get("UNET_NO_STATS_DIRECT") is None
         self._lanes, self._gbufs, self._gptrs = None, [], []
         self.cur_epoch = 0
         model.train()
@@ -78,7 +80,6 @@ class Trainer:
         cur_data_index = self.cur_epoch * p.batch_size
         for g in m.optimizer.param_groups:
             g["lr"] = self.lr_at(self.cur_epoch)
-        self._stats.zero_()
         count = 0
         mine = list(range(self.rank, p.batch_size, self.world_size))
         works = []
@@ -100,6 +101,8 @@ class Trainer:
         # is exactly what one accumulating buffer would hold, so the update is bit-identical to the sequential order.  Not with bnorm
         # (the running statistics are updated in forward order) and not for models without lanes (test stand-ins).
         lanes_on = (self.in_flight > 1 and len(mine) > 1 and hasattr(m, "make_lane") and not m.buffers())
+        if lanes_on or not mine or not self.stats_direct:
+            self._stats.zero_()
         if lanes_on:
             losses_all = self._step_in_lanes(mine, cur_data_index)
             for l in losses_all:
@@ -111,12 +114,16 @@ class Trainer:
             x, t = self.source(cur_data_index + b)
             # the parameters only change at the end of the step (train.cpp:765): this rank's micro-steps 2.. reuse the filter packs of its first
             kw = {"packs_current": True} if (self.packs_reuse and k > 0) else {}
+            first_direct = k == 0 and self.stats_direct
+            if first_direct:
+                kw["losses_out"] = self._stats
             if overlap and k == len(mine) - 1:
                 # gradients accumulate over this rank's micro-steps: only the last backward can hand finished buckets to RCCL
                 losses = m.forward_backward_bucketed(x, t, reduce_bucket, p.cost_ce, p.cost_dice, p.cost_mse, **kw)
             else:
                 losses = m.forward_backward(x, t, p.cost_ce, p.cost_dice, p.cost_mse, **kw)
-            self._stats += losses
+            if not first_direct:
+                self._stats += losses
             count += 1
         if self.comm is not None:
             if not overlap:

@@ -303,14 +303,15 @@ class UNet3d:
         E.check(E.lib.unet_backward_part(plan.handle, pp, go, gp, None, ws.data_ptr(), op_hi, op_lo, _stream_ptr(self._device)))
 
     def forward_backward_bucketed(self, x, target, on_bucket, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0,
-                                  max_buckets=3, packs_current=False):
+                                  max_buckets=3, packs_current=False, losses_out=None):
         """forward_backward with the backward issued in buckets: on_bucket(elem_lo, elem_hi) is called after each part, when the
         gradients flat_grads[elem_lo:elem_hi] are final on the current stream (the data-parallel trainer starts their all-reduce
         there, so that it runs under the rest of the backward)."""
         x = self._check_input(x)
         plan = self.plan_for(x.shape[2:])
         ws = self._workspace(plan)
-        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current)
+        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current,
+                                                     losses_out=losses_out)
         op_hi, elem_hi = 1 << 30, int(self.flat_grads.numel())
         for op_lo, elem_lo in plan.backward_buckets(max_buckets):
             self._run_backward_part(plan, ws, gouts, op_hi, op_lo)
@@ -368,15 +369,17 @@ class UNet3d:
     __call__ = forward
 
     # ---- fused train micro-step (train.cpp:615-706 for one sample) ----
-    def forward_backward(self, x, target, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0, packs_current=False):
+    def forward_backward(self, x, target, cost_ce=True, cost_dice=True, cost_mse=True, collapse_before=0, packs_current=False, losses_out=None):
         """forward + calc_losses over all deep-supervision levels + backward, all in the engine.
         target: int64 {1,D,H,W}.  Returns a device tensor {total, ce0, dice0, mse0}; gradients are ACCUMULATED
         into grads().  packs_current: the caller asserts that a training forward has run on this thread's workspace since the
-        parameters last changed (micro-steps 2.. of one optimizer step): the engine skips the filter repack."""
+        parameters last changed (micro-steps 2.. of one optimizer step): the engine skips the filter repack.  losses_out: a device
+        tensor of 4 floats to receive {total, ce0, dice0, mse0} instead of a fresh one."""
         x = self._check_input(x)
         plan = self.plan_for(x.shape[2:])
         ws = self._workspace(plan)
-        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current)
+        outs, losses, gouts = self._run_forward_loss(plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current,
+                                                     losses_out=losses_out)
         self._run_backward(plan, ws, gouts)
         return losses
 
@@ -388,7 +391,8 @@ class UNet3d:
             self._workspaces[key] = sc
         return sc
 
-    def _run_forward_loss(self, plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current=False, loss_scratch=None):
+    def _run_forward_loss(self, plan, ws, x, target, cost_ce, cost_dice, cost_mse, collapse_before, packs_current=False, loss_scratch=None,
+                          losses_out=None):
         """train-mode forward + calc_losses over all levels in ONE engine call (unet_forward_loss): same numbers as forward() then
         loss(), with the coarse levels' loss kernels issued beside the rest of the decoder."""
         if target.dtype != torch.int64 or target.device != self._device:
@@ -397,10 +401,13 @@ class UNet3d:
         if any(s[1] == 0 for s in plan.output_shapes) or _NO_FUSED_LOSS:   # a level without a head: the two-call path reports it (train.cpp:664-671)
             outs = self._run_forward(plan, ws, x, mode=1 | (E.MODE_PACKS_CURRENT if packs_current else 0))
             losses, gouts = self.loss(outs, target, cost_ce, cost_dice, cost_mse, collapse_before, plan=plan)
+            if losses_out is not None:
+                losses_out.copy_(losses)
+                losses = losses_out
             return outs, losses, gouts
         outs = [torch.empty(s, dtype=torch.float32, device=self._device) for s in plan.output_shapes]
         gouts = [torch.empty_like(o) for o in outs]
-        losses = torch.empty(4, dtype=torch.float32, device=self._device)
+        losses = losses_out if losses_out is not None else torch.empty(4, dtype=torch.float32, device=self._device)
         mask = (1 if cost_ce else 0) | (2 if cost_dice else 0) | (4 if cost_mse else 0)
         mode = 1 | (E.MODE_PACKS_CURRENT if packs_current else 0)
         E.check(E.lib.unet_forward_loss_mode(plan.handle, self._pp, self._bp, x.data_ptr(), E.ptr_array([o.data_ptr() for o in outs]),
