@@ -755,6 +755,26 @@ def test_norm_backward_statistics_in_the_dgrad_epilogue_match_the_separate_pass(
     assert np.abs(g1 - g0).max() <= 5e-3 * np.abs(g0).max()
 
 
+def test_first_conv_weight_gradient_with_the_norm_backward_pass_fused_equals_the_separate_pass(tmp_path):
+    """dL/d(raw output) of the network's first conv is read by nothing but its weight gradient, so that kernel applies the norm
+    backward's element-wise pass while it stages its tiles (NormBwdFuse, engine.cpp) instead of reading a tensor a separate pass wrote;
+    UNET_NO_FIRST_WGRAD_FUSE=1 keeps the separate pass.  The fused form rounds to bf16 exactly where the pass stores, so at 32^3 (both
+    routes take k_norm_bwd_finalize) every gradient is bit-identical; at 16^3 the separate route sums the statistics rows in the
+    fused finalize's order, so the first conv's gradients agree to summation-order noise and everything else exactly."""
+    g1, names = _grads_in_fresh_process(tmp_path, "fused32", 32, {})
+    g0, _ = _grads_in_fresh_process(tmp_path, "separate32", 32, {"UNET_NO_FIRST_WGRAD_FUSE": "1"})
+    assert np.array_equal(g1, g0)
+    assert np.abs(_by_name(g1, names)["encode0.0.weight"]).max() > 0
+    h1, names = _grads_in_fresh_process(tmp_path, "fused16", 16, {})
+    h0, _ = _grads_in_fresh_process(tmp_path, "separate16", 16, {"UNET_NO_FIRST_WGRAD_FUSE": "1"})
+    a1, a0 = _by_name(h1, names), _by_name(h0, names)
+    for nm in a0:
+        if nm.startswith("encode0.0.") or nm.startswith("encode0.1."):
+            assert np.abs(a1[nm] - a0[nm]).max() <= 1e-4 * max(np.abs(a0[nm]).max(), 1e-30), nm
+        else:
+            assert np.array_equal(a1[nm], a0[nm]), nm
+
+
 ARCH_RESUME = ("conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu\n"
                "conv32,ks3,stride2+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu+conv_trans16,ks2,stride2\n"
                "conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu+conv4,ks1,stride1")

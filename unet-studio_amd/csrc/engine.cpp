@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -109,12 +110,15 @@ struct unet_plan {
     // backward side stream: the parameter-gradient kernels (wgrad, its reduce, bias grad) of a layer run beside the
     // dgrad -> norm-backward chain of the next one (they only share read-only inputs); forked / joined with events
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
-    // the training forward packs the filters in two launches on the side stream: the units of the ops before pack_split_op (the
-    // encoder's top levels: a few hundred KB) and the rest (the deep levels and the decoder: ~70 MB); the second is only awaited
-    // by the first op that reads one of its packs, ~0.3 ms into the forward
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr, ev_deep = nullptr, ev_packd = nullptr;
+    // the training forward packs the filters in three launches on the side stream.  The job table holds every op's FORWARD pack first
+    // (op order), then every DGRAD pack: [0, pack_split_blocks) = forward packs of the ops before pack_split_op (the encoder's top
+    // levels: a few hundred KB), [pack_split_blocks, pack_fwd_blocks) = the other forward packs (the deep levels and the decoder; only
+    // awaited by the first op that reads one of them, ~0.3 ms into the forward), [pack_fwd_blocks, pack_blocks) = the dgrad packs (half
+    // of the bytes): nothing reads them before the backward, which waits for ev_packd.  An inference forward packs [0, pack_fwd_blocks) only.
     int pack_split_op = 0;
-    int64_t pack_split_blocks = 0;
+    int64_t pack_split_blocks = 0, pack_fwd_blocks = 0;
+    mutable std::atomic<bool> dgrad_packs_in_flight{false};
     size_t head_off = 0;                     // scratch of the fused head backward (stays on the main stream)
     std::vector<size_t> head_op_off;         // per op: a head's own slab region (its reduce runs on the side stream, later) or SIZE_MAX
 
@@ -125,6 +129,8 @@ struct unet_plan {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_pack) (void)hipEventDestroy(ev_pack);
+        if (ev_deep) (void)hipEventDestroy(ev_deep);
+        if (ev_packd) (void)hipEventDestroy(ev_packd);
         if (side) (void)hipStreamDestroy(side);
     }
 
@@ -140,13 +146,14 @@ struct unet_plan {
     // to the first: the decoder's top levels (their gradients are HELD, see backward()), then the small levels, then the encoder's top
     // levels.  Everything that runs on the side stream while the caller's stream still has latency-bound small kernels ahead is polite;
     // the encoder's top levels are the tail of the step -- nothing is left to run beside them, they get the whole chip.
-    // UNET_SIDE_POLITE=0: none; UNET_POLITE_ALL=1: the tail as well.
+    // UNET_SIDE_POLITE=0: none.  Measured (profiles/r10e_ab_polite_policy.txt): polite for the tail as well is as fast or faster
+    // (2.915-2.93 vs 2.94 ms), so that is the default; UNET_POLITE_TAIL_FULL=1 gives the tail the whole chip.
     std::vector<int> side_polite;
     void choose_polite() {
         side_polite.assign(g.ops.size(), 0);
         const char* e = getenv("UNET_SIDE_POLITE");
         if (e && e[0] == '0' && e[1] == 0) return;
-        static const bool all = getenv("UNET_POLITE_ALL") != nullptr;
+        static const bool all = getenv("UNET_POLITE_TAIL_FULL") == nullptr;
         const int64_t deep = (int64_t)32 * 32 * 32;
         int last_deep = -1;
         for (size_t i = 0; i < g.ops.size(); ++i) {
@@ -351,21 +358,23 @@ struct unet_plan {
         }
         pack_jobs.clear();
         pack_blocks = 0;
-        pack_split_op = -1; pack_split_blocks = 0;
-        for (size_t i = 0; i < g.ops.size(); ++i) {
-            const Op& op = g.ops[i];
-            if ((op.kind != OP_CONV && op.kind != OP_CONVT) || !use_mfma[i]) continue;
-            // first matrix-core op whose output is 16^3 voxels or smaller: everything from here on goes into the second pack launch
-            if (pack_split_op < 0 && g.tensors[op.dst].voxels() <= (int64_t)16 * 16 * 16) { pack_split_op = (int)i; pack_split_blocks = pack_blocks; }
-            PackJob jb[2];
-            int n = op.kind == OP_CONV ? mfma_conv_pack_jobs(op_geom_of(op), dgrad_mfma[i] != 0, jb) : mfma_convt_pack_jobs(op_geom_of(op), jb);
-            for (int k = 0; k < n; ++k) {
-                jb[k].src_off = p_off[op.weight];
-                jb[k].dst_off = (int64_t)(k == 0 ? wm_fwd[i] : wm_dgrad[i]);
-                jb[k].blk0 = pack_blocks;
-                pack_blocks += jb[k].total;
-                pack_jobs.push_back(jb[k]);
+        pack_split_op = -1; pack_split_blocks = 0; pack_fwd_blocks = 0;
+        for (int which = 0; which < 2; ++which) {          // forward packs first, then the dgrad packs
+            for (size_t i = 0; i < g.ops.size(); ++i) {
+                const Op& op = g.ops[i];
+                if ((op.kind != OP_CONV && op.kind != OP_CONVT) || !use_mfma[i]) continue;
+                // first matrix-core op whose output is 16^3 voxels or smaller: its forward pack and the later ops' go into the second launch
+                if (which == 0 && pack_split_op < 0 && g.tensors[op.dst].voxels() <= (int64_t)16 * 16 * 16) { pack_split_op = (int)i; pack_split_blocks = pack_blocks; }
+                PackJob jb[2];
+                int n = op.kind == OP_CONV ? mfma_conv_pack_jobs(op_geom_of(op), dgrad_mfma[i] != 0, jb) : mfma_convt_pack_jobs(op_geom_of(op), jb);
+                if (which >= n) continue;
+                jb[which].src_off = p_off[op.weight];
+                jb[which].dst_off = (int64_t)(which == 0 ? wm_fwd[i] : wm_dgrad[i]);
+                jb[which].blk0 = pack_blocks;
+                pack_blocks += jb[which].total;
+                pack_jobs.push_back(jb[which]);
             }
+            if (which == 0) pack_fwd_blocks = pack_blocks;
         }
     }
 };
@@ -423,7 +432,7 @@ struct Exec {
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
         std::vector<char> fused_dbl(g.norms.size(), 0);     // ... as fp64 rows (the fp32 engine)
         // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
-        bool packed = false, pack_pending = false, pack2_pending = false;
+        bool packed = false, pack_pending = false, pack2_pending = false, dgrad_deferred = false;
         if (p.jobs_dev && packs_current) packed = true;
         else if (p.jobs_dev) {
             bool flat = true;
@@ -433,28 +442,38 @@ struct Exec {
                 // fp32 filter) and its norm; the first kernel that needs packed filters waits for it.  (Eval forwards stay on the
                 // caller's stream: they are re-entrant per workspace, the side stream and its events are per plan.)
                 static const bool no_side = getenv("UNET_NO_SIDE_STREAM") != nullptr;
+                const int njobs = (int)p.pack_jobs.size();
                 if (mode == 1 && p.side && !no_side && !g_prof) {
                     HIP_OK(hipEventRecord(p.ev_fork, s));
                     HIP_OK(hipStreamWaitEvent(p.side, p.ev_fork, 0));
                     static const bool one_pack = getenv("UNET_PACK_ONE_LAUNCH") != nullptr;
                     if (p.pack_split_op > 0 && p.pack_split_blocks > 0 && !one_pack) {
-                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_split_blocks, p.side);
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_split_blocks, p.side);
                         HIP_OK(hipEventRecord(p.ev_join, p.side));
-                        // the deep levels' packs (most of the bytes) are not needed for the next ~0.3 ms: a bounded grid, so that the first
-                        // full-resolution convs keep the CUs (UNET_PACK_GRID; 0 = a block per unit)
+                        // UNET_PACK_GRID: bound on the number of blocks of the later launches (0 = a block per unit; measured: no gain)
                         static const int pack_grid = getenv("UNET_PACK_GRID") ? atoi(getenv("UNET_PACK_GRID")) : 0;
-                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks - p.pack_split_blocks, p.side,
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_fwd_blocks - p.pack_split_blocks, p.side,
                                                  p.pack_split_blocks, pack_grid);
                         HIP_OK(hipEventRecord(p.ev_pack, p.side));
                         pack2_pending = true;
+                        // the dgrad packs: right away.  (UNET_PACK_DGRAD_LATE=1: when the caller's stream reaches pack_split_op, beside the small
+                        // levels instead of beside the first full-resolution convs -- measured 2.925-2.935 ms against 2.915: the 5800 short
+                        // blocks delay the small levels' latency-bound kernels by more than they cost the bandwidth-bound ones.)
+                        static const bool early = getenv("UNET_PACK_DGRAD_LATE") == nullptr;
+                        if (early) {
+                            launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks, pack_grid);
+                            HIP_OK(hipEventRecord(p.ev_packd, p.side));
+                            p.dgrad_packs_in_flight.store(true);
+                        } else dgrad_deferred = true;
                     } else {
-                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, p.side);
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks, p.side);
                         HIP_OK(hipEventRecord(p.ev_join, p.side));
                     }
                     pack_pending = true;
                 } else {
+                    // an inference forward never reads a dgrad pack
                     ProfScope ps(-1, UNET_PROF_OTHER, s);
-                    launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks, s);
+                    launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, mode == 1 ? p.pack_blocks : p.pack_fwd_blocks, s);
                 }
                 packed = true;
             }
@@ -463,8 +482,19 @@ struct Exec {
             if (pack_pending) { HIP_OK(hipStreamWaitEvent(s, p.ev_join, 0)); pack_pending = false; }
             if (pack2_pending && op_index >= p.pack_split_op) { HIP_OK(hipStreamWaitEvent(s, p.ev_pack, 0)); pack2_pending = false; }
         };
+        auto launch_dgrad_packs = [&]() {      // behind everything the caller's stream has been given so far
+            if (!dgrad_deferred) return;
+            dgrad_deferred = false;
+            static const int pack_grid = getenv("UNET_PACK_GRID") ? atoi(getenv("UNET_PACK_GRID")) : 0;
+            HIP_OK(hipEventRecord(p.ev_deep, s));
+            HIP_OK(hipStreamWaitEvent(p.side, p.ev_deep, 0));
+            launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks, pack_grid);
+            HIP_OK(hipEventRecord(p.ev_packd, p.side));
+            p.dgrad_packs_in_flight.store(true);
+        };
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
+            if ((int)i == p.pack_split_op) launch_dgrad_packs();
             ProfScope ps((int)i, (op.kind == OP_CONV || op.kind == OP_CONVT) ? UNET_PROF_CONV_FWD : op.kind == OP_NORM ? UNET_PROF_NORM_FWD : UNET_PROF_OTHER, s);
             switch (op.kind) {
                 case OP_PACK_INPUT:
@@ -592,11 +622,14 @@ struct Exec {
             if (on_head && op.out_level >= 0 && outs && outs[op.out_level] && (op.kind == OP_CONV || op.kind == OP_CONVT || op.kind == OP_EXPORT))
                 (*on_head)(op.out_level);
         }
+        launch_dgrad_packs();
         need_packs();   // nothing consumed the packs (no MFMA op): still order the caller's stream after the side stream
     }
 
     // g[t] holds dL/d(view of t); turn it into dL/d(raw t) (and accumulate the norm's affine gradients)
-    void view_backward(int t, const float* const* params, float* const* gparams) {
+    // no_apply: stop after the finalize (coef(T.norm) is final; dgamma / dbeta accumulated) -- the element-wise pass is fused into the one
+    // consumer of dL/d(raw t) (the first conv's weight gradient)
+    void view_backward(int t, const float* const* params, float* const* gparams, bool no_apply = false) {
         const Tensor& T = p.g.tensors[t];
         if (T.norm >= 0) {
             const Norm& n = p.g.norms[T.norm];
@@ -609,11 +642,12 @@ struct Exec {
             }
             if (have > 0) rows = have;
             else launch_norm_bwd_partial(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), T.act, partial(), s);
-            if (launch_norm_bwd_finalize_apply(p.dtype, partial(), rows, T.C, T.voxels(), params[n.gamma], stat(T.norm),
-                                               coef(T.norm), gparams[n.gamma], gparams[n.beta], gptr(t), tptr(t), T.act, s))
+            if (!no_apply && launch_norm_bwd_finalize_apply(p.dtype, partial(), rows, T.C, T.voxels(), params[n.gamma], stat(T.norm),
+                                                            coef(T.norm), gparams[n.gamma], gparams[n.beta], gptr(t), tptr(t), T.act, s))
                 return;
             launch_norm_bwd_finalize(partial(), rows, T.C, T.voxels(), params[n.gamma], stat(T.norm), coef(T.norm),
                                      gparams[n.gamma], gparams[n.beta], s, p.dtype == UNET_DTYPE_F32);
+            if (no_apply) return;
             launch_norm_bwd_apply(p.dtype, gptr(t), tptr(t), T.C, T.voxels(), stat(T.norm), coef(T.norm), T.act, s);
         } else if (T.act != ACT_NONE) {
             launch_act_bwd(p.dtype, gptr(t), tptr(t), T.act, T.numel(), s);
@@ -626,6 +660,8 @@ struct Exec {
     void backward(const float* const* params, const float* const* grad_outs, float* const* gparams, float* grad_x, int op_hi = 1 << 30,
                   int op_lo = 0) {
         const Graph& g = p.g;
+        // the dgrad filter packs of this step were launched on the side stream in the middle of the forward
+        if (p.dgrad_packs_in_flight.exchange(false)) HIP_OK(hipStreamWaitEvent(s, p.ev_packd, 0));
         std::vector<char> init(g.tensors.size(), 0);
         auto dst_of = [&](int t) {
             DstGrad d;
@@ -763,7 +799,16 @@ struct Exec {
                 init[t] = 1;
             }
             if (!g.tensors[t].needs_grad || !init[t]) continue;
-            if (!dry) { ProfScope ps(i, UNET_PROF_NORM_BWD, s); view_backward(t, params, gparams); }
+            // The network's first conv with a norm behind it: dL/d(raw output) is only read by its weight gradient (the input needs no
+            // gradient), which applies the norm backward's element-wise pass itself (NormBwdFuse) -- see the OP_CONV case below
+            bool first_fused = false;
+            if (!dry && op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && p.dtype == UNET_DTYPE_BF16 && g.tensors[t].norm >= 0 && op.nsrc == 1 &&
+                !g.tensors[op.src[0]].needs_grad && sb != s && p.wz_off[i] != SIZE_MAX && g.tensors[t].C % 8 == 0) {
+                static const bool off = getenv("UNET_NO_FIRST_WGRAD_FUSE") != nullptr;
+                SrcDesc sd0 = src(op.src[0]);
+                first_fused = !off && conv_first_wgrad_mfma_supported(p.dtype, geom(op), &sd0, 1);
+            }
+            if (!dry) { ProfScope ps(i, UNET_PROF_NORM_BWD, s); view_backward(t, params, gparams, first_fused); }
             switch (op.kind) {
                 case OP_CONV:
                 case OP_CONVT: {
@@ -779,7 +824,10 @@ struct Exec {
                     if (!dry && !any && sb != s && op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && p.wz_off[i] != SIZE_MAX &&
                         conv_first_wgrad_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
                         ProfScope pw(i, UNET_PROF_WGRAD, s);
-                        launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wz_off[i], s, false);
+                        const Tensor& To = g.tensors[t];
+                        NormBwdFuse nf = {tptr(t), first_fused ? stat(To.norm) : nullptr, first_fused ? coef(To.norm) : nullptr, To.act};
+                        launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wz_off[i], s, false,
+                                                     first_fused ? &nf : nullptr);
                     } else
                     if (!dry) {
                         const int64_t vox = (int64_t)cg.Do * cg.Ho * cg.Wo;
@@ -966,6 +1014,8 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
             HIP_OK(hipEventCreateWithFlags(&p->ev_fork, evf));
             HIP_OK(hipEventCreateWithFlags(&p->ev_join, evf));
             HIP_OK(hipEventCreateWithFlags(&p->ev_pack, evf));
+            HIP_OK(hipEventCreateWithFlags(&p->ev_deep, evf));
+            HIP_OK(hipEventCreateWithFlags(&p->ev_packd, evf));
             HIP_OK(hipMalloc((void**)&p->segs_dev, segs.size() * sizeof(SgdSeg)));
             HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
             if (!p->wz_jobs.empty()) {

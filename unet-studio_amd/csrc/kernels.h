@@ -202,8 +202,11 @@ void launch_head_bwd_reduce(const ConvGeom& g, float* dw, float* db, const void*
 // wgrad (+ bias grad) of the first conv (Cin = 1, 3x3x3 stride 1, Cout 16 or 32, plain bf16 input) on the matrix cores
 bool conv_first_wgrad_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g);
+// nb_fuse: dy is dL/d(activated view); the norm backward's element-wise pass (k_norm_bwd_apply8's arithmetic with the coefficients
+// k_norm_bwd_finalize left) is applied as the tiles are staged -- the same bits as running that pass first, without its 3 tensor transfers
+struct NormBwdFuse { const void* u; const float* stat; const float* coef; int act; };
 void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s,
-                                  bool defer_reduce = false);
+                                  bool defer_reduce = false, const NormBwdFuse* nb_fuse = nullptr);
 bool wgrad_small_supported(const ConvGeom& g, int nsrc);
 size_t wgrad_small_scratch_bytes(const ConvGeom& g);
 void launch_conv_wgrad_small(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db,

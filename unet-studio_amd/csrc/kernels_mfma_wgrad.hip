@@ -526,8 +526,15 @@ struct FirstWgradArgs {
     float* slab;        // [gridDim.x][27 * Cout]
     float* bslab;       // [gridDim.x][Cout]
     int tiles_x, tiles_y, tiles_z;
+    // FUSE: dy is dL/d(activated view) of the conv's output and the norm backward's element-wise pass is applied as the tile is staged
+    // (k_norm_bwd_apply8's arithmetic, rounded to bf16 exactly as that pass stores it: the same bits reach the MFMAs) -- the first conv's
+    // dL/d(raw output) has no other reader, so the pass (read 2, write 1 tensor of 64 MB at 128^3) is never run.
+    const void* u;      // raw conv output, bf16 [D][H][W][Cout]
+    const float* stat;  // [4][Cout] mean, rstd, scale, shift
+    const float* coef;  // [3][Cout] k_norm_bwd_finalize's coefficients
+    int act;
 };
-template <int NT>
+template <int NT, bool FUSE>
 __global__ void __launch_bounds__(256, 2) k_wgrad_first_mfma(FirstWgradArgs a) {
     constexpr int TZ = 2, TY = 8, TX = 32, HZ = TZ + 2, HY = TY + 2, NROW = TZ * TY, CO = 16 * NT;
     constexpr int XCOPY = HZ * HY * TX;                 // elements of one shifted copy of the halo
@@ -562,7 +569,23 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_first_mfma(FirstWgradArgs a) {
     constexpr int XI = (HZ * HY * (TX + 2) + 255) / 256, DI = NROW * TX * (CO / 8) / 256;
     static_assert(NROW * TX * (CO / 8) % 256 == 0, "dy units per thread");
     unsigned short xr[XI];
-    uint4 dr[DI];
+    uint4 dr[DI], ur[FUSE ? DI : 1];
+    unsigned dmask = 0;
+    // a thread's dy units all lie in the same 8-channel group (256 % (CO / 8) == 0): its coefficients stay in registers
+    float cA[8], cB[8], cD[8], csc[8], csh[8];
+    if constexpr (FUSE) {
+        const int c0 = (tid % (CO / 8)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            const float mean = a.stat[c], rstd = a.stat[CO + c];
+            csc[e] = a.stat[2 * CO + c]; csh[e] = a.stat[3 * CO + c];
+            cA[e] = a.coef[c];
+            cB[e] = -a.coef[c] * rstd * a.coef[2 * CO + c];
+            cD[e] = -a.coef[c] * (a.coef[CO + c] - mean * rstd * a.coef[2 * CO + c]);
+        }
+    }
+    const char* ub = (const char*)a.u;
     auto gload = [&](int t) {
         const int x0 = (t % a.tiles_x) * TX, y0 = ((t / a.tiles_x) % a.tiles_y) * TY, z0 = (t / (a.tiles_x * a.tiles_y)) * TZ;
 #pragma unroll
@@ -580,8 +603,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_first_mfma(FirstWgradArgs a) {
             const int u = tid + i * 256;
             const int c8 = u % (CO / 8), vx = (u / (CO / 8)) % TX, row = u / ((CO / 8) * TX);
             const int gz = z0 + row / TY, gy = y0 + row % TY, gx = x0 + vx;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (gz < g.D && gy < g.H && gx < g.W) v = *(const uint4*)(dyb + ((((size_t)gz * g.H + gy) * g.W + gx) * CO + c8 * 8) * 2);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u), w = make_uint4(0u, 0u, 0u, 0u);
+            const bool in = gz < g.D && gy < g.H && gx < g.W;
+            const size_t off = ((((size_t)gz * g.H + gy) * g.W + gx) * CO + c8 * 8) * 2;
+            if (in) v = *(const uint4*)(dyb + off);
+            if constexpr (FUSE) {
+                if (in) w = *(const uint4*)(ub + off);
+                ur[i] = w;
+                dmask = in ? (dmask | (1u << i)) : (dmask & ~(1u << i));   // units outside the volume keep dy = 0
+            }
             dr[i] = v;
         }
     };
@@ -605,6 +635,21 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_first_mfma(FirstWgradArgs a) {
             const int u = tid + i * 256;
             const int c8 = u % (CO / 8), vx = (u / (CO / 8)) % TX, row = u / ((CO / 8) * TX);
             unsigned* d = (unsigned*)(sm + DY_OFF + (row * TX + vx) * VSB + c8 * 16);
+            if constexpr (FUSE) {
+                if ((dmask >> i) & 1u) {
+                    const unsigned gu[4] = {dr[i].x, dr[i].y, dr[i].z, dr[i].w}, uu[4] = {ur[i].x, ur[i].y, ur[i].z, ur[i].w};
+                    unsigned o[4];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float g0 = __uint_as_float(gu[e / 2] << 16), g1 = __uint_as_float(gu[e / 2] & 0xffff0000u);
+                        const float u0 = __uint_as_float(uu[e / 2] << 16), u1 = __uint_as_float(uu[e / 2] & 0xffff0000u);
+                        const float r0 = fmaf(cA[e] * g0, act_d(fmaf(u0, csc[e], csh[e]), a.act), fmaf(cB[e], u0, cD[e]));
+                        const float r1 = fmaf(cA[e + 1] * g1, act_d(fmaf(u1, csc[e + 1], csh[e + 1]), a.act), fmaf(cB[e + 1], u1, cD[e + 1]));
+                        o[e / 2] = (unsigned)__bfloat16_as_ushort(__float2bfloat16(r0)) | ((unsigned)__bfloat16_as_ushort(__float2bfloat16(r1)) << 16);
+                    }
+                    dr[i] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
             d[0] = dr[i].x; d[1] = dr[i].y; d[2] = dr[i].z; d[3] = dr[i].w;
         }
     };
@@ -670,15 +715,22 @@ size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g) { return (size_t)f
 // dw += , db += (db may be null); scratch: conv_first_wgrad_mfma_scratch_bytes
 int conv_first_wgrad_splits(const ConvGeom& g) { return first_wgrad_blocks(g); }
 void launch_conv_first_wgrad_mfma(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, float* db, void* scratch, hipStream_t s,
-                                  bool defer_reduce) {
+                                  bool defer_reduce, const NormBwdFuse* nb_fuse) {
     FirstWgradArgs a;
     a.g = g; a.x = src[0].ptr; a.dy = dy; a.slab = (float*)scratch;
+    a.u = nb_fuse ? nb_fuse->u : nullptr; a.stat = nb_fuse ? nb_fuse->stat : nullptr; a.coef = nb_fuse ? nb_fuse->coef : nullptr;
+    a.act = nb_fuse ? nb_fuse->act : 0;
     a.tiles_x = (g.W + 31) / 32; a.tiles_y = (g.H + 7) / 8; a.tiles_z = (g.D + 1) / 2;
     const int nb = first_wgrad_blocks(g);
     const int64_t O = 27 * g.Cout;
     a.bslab = a.slab + (size_t)nb * O;
-    if (g.Cout == 16) k_wgrad_first_mfma<1><<<nb, 256, 0, s>>>(a);
-    else k_wgrad_first_mfma<2><<<nb, 256, 0, s>>>(a);
+    if (nb_fuse) {
+        if (g.Cout == 16) k_wgrad_first_mfma<1, true><<<nb, 256, 0, s>>>(a);
+        else k_wgrad_first_mfma<2, true><<<nb, 256, 0, s>>>(a);
+    } else {
+        if (g.Cout == 16) k_wgrad_first_mfma<1, false><<<nb, 256, 0, s>>>(a);
+        else k_wgrad_first_mfma<2, false><<<nb, 256, 0, s>>>(a);
+    }
     if (!defer_reduce) wgrad_reduce(a.slab, db ? a.bslab : nullptr, nb, O, g.Cout, dw, db, s);
 }
 
