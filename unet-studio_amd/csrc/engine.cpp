@@ -149,8 +149,26 @@ struct unet_plan {
     // UNET_SIDE_POLITE=0: none.  Measured (profiles/r10e_ab_polite_policy.txt): polite for the tail as well is as fast or faster
     // (2.915-2.93 vs 2.94 ms), so that is the default; UNET_POLITE_TAIL_FULL=1 gives the tail the whole chip.
     std::vector<int> side_polite;
+    // Weight gradients that run on the CALLER's stream (full occupancy, slab summed there too): the stride-2 conv at the top of the encoder.
+    // Its kernel becomes ready together with its own dgrad at the tail of the backward, where nothing latency-bound is left to hide it
+    // behind, and the two side by side took longer than one after the other (154 us against 55 + 49: both stream the same 64-MB tensors
+    // through the same L2s; profiles/r10h_ab_tail_on_main.txt: step 2.92 -> 2.88 ms).  UNET_TAIL_MAIN=<bit mask> overrides: bit k = the
+    // k-th conv after the first one, in forward order, before the small levels (0 = none).
+    std::vector<char> wgrad_on_main;
     void choose_polite() {
         side_polite.assign(g.ops.size(), 0);
+        wgrad_on_main.assign(g.ops.size(), 0);
+        {
+            static const int mask = getenv("UNET_TAIL_MAIN") ? atoi(getenv("UNET_TAIL_MAIN")) : -1;
+            int k = -1;
+            for (size_t i = 0; i < g.ops.size(); ++i) {
+                const Op& op = g.ops[i];
+                if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
+                if (g.tensors[op.dst].voxels() <= (int64_t)32 * 32 * 32) break;
+                if (k >= 0 && (mask >= 0 ? ((mask >> k) & 1) != 0 : (op.kind == OP_CONV && op.stride == 2))) wgrad_on_main[i] = 1;
+                ++k;
+            }
+        }
         const char* e = getenv("UNET_SIDE_POLITE");
         if (e && e[0] == '0' && e[1] == 0) return;
         static const bool all = getenv("UNET_POLITE_TAIL_FULL") == nullptr;
@@ -165,7 +183,7 @@ struct unet_plan {
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
-            side_polite[i] = (all || g.tensors[op.dst].voxels() <= deep || (int)i > last_deep) ? 1 : 0;
+            side_polite[i] = (all || g.tensors[op.dst].voxels() <= deep || (int)i > last_deep) && !wgrad_on_main[i] ? 1 : 0;
         }
     }
 
@@ -485,7 +503,7 @@ struct Exec {
         auto launch_dgrad_packs = [&]() {      // behind everything the caller's stream has been given so far
             if (!dgrad_deferred) return;
             dgrad_deferred = false;
-            static const int pack_grid = getenv("UNET_PACK_GRID") ? atoi(getenv("UNET_PACK_GRID")) : 0;
+            static const int pack_grid = getenv("UNET_PACK_GRID_LATE") ? atoi(getenv("UNET_PACK_GRID_LATE")) : 0;
             HIP_OK(hipEventRecord(p.ev_deep, s));
             HIP_OK(hipStreamWaitEvent(p.side, p.ev_deep, 0));
             launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks, pack_grid);
@@ -720,6 +738,9 @@ struct Exec {
                     launch_conv_first_wgrad_mfma(cg, sd, gptr(t), gparams[op.weight], gparams[op.bias],
                                                  ws + (defer ? p.wz_off[i] : p.wgrad_off), sb, defer);
                     if (defer) { wz_ran[p.wz_job_of_op[i]] = 1; ++wz_pending; }
+                } else if (p.wgrad_mfma[i] && p.wgrad_on_main[i] && p.wz_off[i] != SIZE_MAX) {
+                    // experiment: kernel and its slab sum on the caller's stream (slab in the op's own region: the shared scratch is the side stream's)
+                    launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wz_off[i], s, false, 0);
                 } else if (p.wgrad_mfma[i]) {
                     const bool defer = gflat && p.wz_job_of_op[i] >= 0;   // slab only: summed by the batched reduce below
                     launch_mfma_conv_wgrad(cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias],
