@@ -817,7 +817,8 @@ static void launch_wgrad_cfg(const MfmaWgradArgs& a0, const WgradCfg& c, hipStre
     static_assert(lds <= 80 * 1024, "two blocks per CU");
     static std::atomic<uint64_t> attr_done{0};
     const int lds_launch = polite_lds((int)lds, c.polite);
-    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, lds_launch);
+    // the attribute is set once per kernel: to the polite size, whichever kind of launch comes first
+    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ>, polite_lds((int)lds, 1));
     dim3 grid((unsigned)c.nsplit, (unsigned)c.gy);
     a.direct = c.direct;
     k_mfma_wgrad<S, KD, PAD, BZ, BY, BX, PI, PJ><<<grid, 256, lds_launch, s>>>(a);

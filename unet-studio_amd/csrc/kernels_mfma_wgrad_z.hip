@@ -441,7 +441,7 @@ static void launch_wz(const WgradZArgs& a, const WgradZCfg& c, hipStream_t s, in
     static_assert(lds <= 80 * 1024, "LDS budget");
     static std::atomic<uint64_t> attr_done{0};
     const int lds_launch = (WK * PA * PB == 4) ? polite_lds(lds, polite) : lds;
-    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, lds_launch);
+    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, polite_lds(lds, 1));   // once per kernel: the polite size
     static const bool dbg = getenv("UNET_WZ_DEBUG") != nullptr;
     if (dbg) {
         int nb = -1;
