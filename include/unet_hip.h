@@ -145,6 +145,21 @@ int unet_forward_loss_mode(const unet_plan* plan, const float* const* params, fl
                            const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
                            void* loss_scratch, void* workspace, int mode, void* stream);
 
+/* EXPERIMENTAL (micro-steps in flight on disjoint parts of the chip; measured in DESIGN.md section 6): a stream confined to the CUs
+ * [cu_first, cu_first + cu_count) of EVERY XCD (32 per XCD on MI355X; the indices wrap), and the same for a plan's side stream.  Such a
+ * stream synchronizes with the NULL stream (hipExtStreamCreateWithCUMask takes no flags): use it with callers on non-NULL streams. */
+int unet_stream_create_cu_range(int device, int cu_first, int cu_count, void** stream);
+int unet_stream_destroy(void* stream);
+int unet_plan_side_cu_range(unet_plan* plan, int cu_first, int cu_count);
+
+/* The filter packs of `workspace` made from the current parameter values, on `stream` (what a mode-1 forward without
+ * UNET_MODE_PACKS_CURRENT does first, on the plan's side stream, beside its first kernels).  A trainer may call it right behind
+ * unet_sgd_step -- the parameters are still in the last-level cache -- and give the next forward on this workspace
+ * UNET_MODE_PACKS_CURRENT.  with_dgrad = 0: the forward packs only (all an inference forward reads).  *made = 1 when the packs were
+ * made, 0 when this plan has no batched pack (fp32 engine, parameters not in one flat buffer): the caller must NOT claim
+ * UNET_MODE_PACKS_CURRENT then. */
+int unet_pack_filters(const unet_plan* plan, const float* const* params, void* workspace, int with_dgrad, int* made, void* stream);
+
 /* Gradient buffers of micro-steps that ran side by side (each into a buffer of its own) -> the ONE buffer the step epilogue reads:
  * out[i] = ((bufs[0][i] + bufs[1][i]) + bufs[2][i]) + ... in fp32, exactly the association a single buffer ends up with when the
  * micro-steps accumulate into it one after the other (train.cpp:604-606,706: .grad accumulates; 0 + x == x), so the update is

@@ -839,14 +839,41 @@ def test_micro_steps_reusing_the_filter_packs_equal_repacking(dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_micro_steps_in_flight_equal_the_sequential_order(dt):
+def test_filter_packs_made_behind_the_update_equal_the_forwards_own(dt):
+    """unet_pack_filters (include/unet_hip.h): a trainer may make the workspace's filter packs right behind the update and give the next
+    step's first forward UNET_MODE_PACKS_CURRENT.  Three steps with Trainer.pack_after_update must give bit-identical parameters and
+    loss statistics; the fp32 engine has no batched pack: pack_filters reports so and the forward repacks as before."""
+    ma, ta = _trainer(dt, batch=2)
+    mb, tb = _trainer(dt, batch=2)
+    ta.pack_after_update = True
+    assert not tb.pack_after_update
+    for _ in range(3):
+        sa, sb = ta.step().clone(), tb.step().clone()
+        assert torch.equal(sa, sb)
+        assert (ta._packed_size == (16, 16, 16)) == (dt == "bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(ma.flat_params, mb.flat_params)
+
+
+@pytest.mark.parametrize("lane_cus", [0, 12])
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_micro_steps_in_flight_equal_the_sequential_order(dt, lane_cus, monkeypatch):
     """Two micro-steps of one optimizer step side by side on one GPU (Trainer.in_flight = 2: two lanes = two streams, two plans, two
     workspaces; every micro-step writes a gradient buffer of its own; unet_sum_buffers adds them in micro-step order) must give the
     parameters of the sequential order BIT FOR BIT: ((g0 + g1) + g2) + ... is what one accumulating buffer holds (train.cpp:604-606,
     756-761).  Batch 5 = an odd count (lanes of 3 and 2 micro-steps), three steps (the buffers are cleared and reused)."""
+    if lane_cus:   # the lanes (stream and plan side stream) on disjoint CU ranges of every XCD (unet_stream_create_cu_range); such streams
+        monkeypatch.setenv("UNET_LANE_CUS", str(lane_cus))   # synchronize with the NULL stream, so the trainer runs on a stream of torch's pool
     ma, ta = _trainer(dt, batch=5)
     mb, tb = _trainer(dt, batch=5)
     ta.in_flight, tb.in_flight = 2, 1
+    torch.cuda.synchronize()
+    with torch.cuda.stream(torch.cuda.Stream(DEV)):
+        _in_flight_steps(ma, ta, mb, tb)
+    torch.cuda.synchronize()
+
+
+def _in_flight_steps(ma, ta, mb, tb):
     for _ in range(3):
         sa, sb = ta.step().clone(), tb.step().clone()
         assert torch.allclose(sa, sb, rtol=1e-6, atol=1e-7)

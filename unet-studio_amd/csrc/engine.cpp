@@ -964,6 +964,7 @@ int unet_device_info(int device, char* name, size_t name_len, size_t* total_mem,
     return 0;
 }
 
+static bool create_cu_range_stream(int device, int cu_first, int cu_count, hipStream_t* out);
 int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W, int dtype, int device, int impl, unet_plan** out) {
     if (!arch || !out) return fail("unet_plan_create: null argument");
     if (dtype != UNET_DTYPE_F32 && dtype != UNET_DTYPE_BF16) return fail("unet_plan_create: unknown dtype");
@@ -1014,20 +1015,7 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
             // caller's stream always finds CUs whose registers and LDS are not held by long weight-gradient blocks.  0 = all CUs.
             static const int side_cus = getenv("UNET_SIDE_CUS") ? atoi(getenv("UNET_SIDE_CUS")) : 0;
             static const int side_cu0 = getenv("UNET_SIDE_CU_FIRST") ? atoi(getenv("UNET_SIDE_CU_FIRST")) : 0;
-            hipDeviceProp_t prop;
-            bool masked = false;
-            if (side_cus > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount % 8 == 0) {
-                const int per_xcd = prop.multiProcessorCount / 8;
-                if (side_cus < per_xcd) {
-                    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
-                    for (int c = 0; c < side_cus; ++c) {
-                        const int cu = (side_cu0 + c) % per_xcd;
-                        for (int x = 0; x < 8; ++x) { const int bit = cu * 8 + x; mask[bit / 32] |= 1u << (bit % 32); }
-                    }
-                    masked = hipExtStreamCreateWithCUMask(&p->side, (uint32_t)mask.size(), mask.data()) == hipSuccess;
-                    if (!masked) (void)hipGetLastError();
-                }
-            }
+            const bool masked = side_cus > 0 && create_cu_range_stream(device, side_cu0, side_cus, &p->side);
             if (!masked) HIP_OK(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, pr_least));
             // the plan's events only order its two streams on ONE device: no host ever waits on them, so the system-scope fence a
             // default event performs when it is recorded (cache write-back for host visibility) is not needed (UNET_EVENT_SYSFENCE=1 keeps it)
@@ -1367,6 +1355,67 @@ int unet_forward_loss_mode(const unet_plan* p, const float* const* params, float
         HIP_OK(hipStreamWaitEvent(s, p->ev_join, 0));
         lr.level_finish(0, 0, s);
         check_launch();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+// A stream confined to CUs [cu_first, cu_first + cu_count) of EVERY XCD (indices wrap inside the XCD).  Bit i of the HIP CU mask is CU
+// i / 8 of XCD i % 8 on this part (profiles/tools/cu_mask_probe.hip); every XCD keeps at least one CU, or the driver ignores the mask.
+// Such a stream is created without hipStreamNonBlocking (the API has no flags): it synchronizes with the NULL stream like any blocking stream.
+static bool create_cu_range_stream(int device, int cu_first, int cu_count, hipStream_t* out) {
+    hipDeviceProp_t prop;
+    if (cu_count <= 0 || hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount % 8 != 0) return false;
+    const int per_xcd = prop.multiProcessorCount / 8;
+    if (cu_count >= per_xcd) return false;
+    std::vector<uint32_t> mask((prop.multiProcessorCount + 31) / 32, 0u);
+    for (int c = 0; c < cu_count; ++c) {
+        const int cu = ((cu_first + c) % per_xcd + per_xcd) % per_xcd;
+        for (int x = 0; x < 8; ++x) { const int bit = cu * 8 + x; mask[bit / 32] |= 1u << (bit % 32); }
+    }
+    if (hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
+
+int unet_stream_create_cu_range(int device, int cu_first, int cu_count, void** stream) {
+    try {
+        if (!stream) throw std::runtime_error("unet_stream_create_cu_range: null argument");
+        DeviceGuard dg(device);
+        hipStream_t st = nullptr;
+        if (!create_cu_range_stream(device, cu_first, cu_count, &st)) throw std::runtime_error("unet_stream_create_cu_range: the device / driver does not take this CU range");
+        *stream = (void*)st;
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+int unet_stream_destroy(void* stream) {
+    if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return fail("hipStreamDestroy failed");
+    return 0;
+}
+int unet_plan_side_cu_range(unet_plan* p, int cu_first, int cu_count) {
+    try {
+        if (!p) throw std::runtime_error("unet_plan_side_cu_range: null plan");
+        if (!p->side) return 0;
+        DeviceGuard dg(p->device);
+        hipStream_t st = nullptr;
+        if (!create_cu_range_stream(p->device, cu_first, cu_count, &st)) throw std::runtime_error("unet_plan_side_cu_range: the device / driver does not take this CU range");
+        HIP_OK(hipStreamSynchronize(p->side));
+        HIP_OK(hipStreamDestroy(p->side));
+        p->side = st;
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int unet_pack_filters(const unet_plan* p, const float* const* params, void* workspace, int with_dgrad, int* made, void* stream) {
+    try {
+        if (!p || !params || !workspace || !made) throw std::runtime_error("unet_pack_filters: null argument");
+        *made = 0;
+        if (!p->jobs_dev || p->pack_jobs.empty()) return 0;
+        for (size_t i = 0; i < p->g.params.size(); ++i)
+            if (params[i] != params[0] + p->p_off[i]) return 0;
+        DeviceGuard dg(p->device);
+        launch_mfma_pack_batched(params[0], workspace, p->jobs_dev, (int)p->pack_jobs.size(), with_dgrad ? p->pack_blocks : p->pack_fwd_blocks,
+                                 (hipStream_t)stream);
+        check_launch();
+        *made = 1;
         return 0;
     } catch (const std::exception& e) { return fail(e.what()); }
 }

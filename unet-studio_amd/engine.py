@@ -70,6 +70,10 @@ _sig("unet_loss", _i, _vp, _pp, _vp, _i, _i, _pp, _vp, _vp, _vp)
 _sig("unet_forward_loss", _i, _vp, _pp, _pp, _vp, _pp, _vp, _i, _i, _pp, _vp, _vp, _vp, _vp)
 _sig("unet_forward_loss_mode", _i, _vp, _pp, _pp, _vp, _pp, _vp, _i, _i, _pp, _vp, _vp, _vp, _i, _vp)
 _sig("unet_sum_buffers", _i, _pp, _i, _vp, C.c_int64, _i, _vp)
+_sig("unet_stream_create_cu_range", _i, _i, _i, _i, _vp)
+_sig("unet_stream_destroy", _i, _vp)
+_sig("unet_plan_side_cu_range", _i, _vp, _i, _i)
+_sig("unet_pack_filters", _i, _vp, _vp, _vp, _i, _vp, _vp)
 _sig("unet_sgd_step", _i, _vp, _vp, _vp, _vp, _f, _f, _i, _f, _f, _f, _vp, _vp, _vp)
 _sig("unet_set_error", None, C.c_char_p)
 _sig("unet_comm_unique_id", _i, _vp)
@@ -100,7 +104,7 @@ EXPORTS = [
     "unet_plan_param_shape", "unet_plan_param_name", "unet_plan_param_decay", "unet_plan_param_fan_in", "unet_plan_buffer_count",
     "unet_plan_buffer_shape", "unet_plan_output_count", "unet_plan_output_shape", "unet_plan_workspace_bytes",
     "unet_plan_flops", "unet_plan_describe", "unet_plan_op_count", "unet_plan_op_info", "unet_profile_begin", "unet_profile_end", "unet_forward", "unet_backward", "unet_backward_part", "unet_plan_backward_buckets", "unet_loss_scratch_bytes", "unet_loss", "unet_forward_loss", "unet_forward_loss_mode", "unet_sum_buffers",
-    "unet_sgd_step", "unet_set_error", "unet_comm_unique_id", "unet_comm_create", "unet_comm_create_all", "unet_comm_destroy", "unet_comm_rank",
+    "unet_sgd_step", "unet_pack_filters", "unet_stream_create_cu_range", "unet_stream_destroy", "unet_plan_side_cu_range", "unet_set_error", "unet_comm_unique_id", "unet_comm_create", "unet_comm_create_all", "unet_comm_destroy", "unet_comm_rank",
     "unet_allreduce_grads", "unet_allreduce_grads_all", "unet_comm_broadcast", "unet_comm_join", "unet_op_scratch_bytes", "unet_op_conv3d_fwd", "unet_op_conv3d_fwd_fused", "unet_op_conv3d_pack", "unet_op_conv3d_fwd_packed", "unet_op_conv3d_bwd_data", "unet_op_conv3d_bwd_weight",
     "unet_op_convt_fwd", "unet_op_convt_bwd_data", "unet_op_convt_bwd_weight", "unet_op_pack_ndhwc", "unet_op_unpack_ncdhw",
 ]

@@ -62,6 +62,10 @@ class Trainer:
         # samples that share the chip thrash each other's L2 patches and LDS occupancy)
         self.in_flight = max(1, int(os.environ.get("UNET_MICRO_IN_FLIGHT", "1")))
         # the engine writes the first micro-step's {total, ce, dice, mse} straight into the step's statistics (no zeroing launch, no add)
+        # UNET_PACK_AFTER_UPDATE=1 (experiment): the filter packs are made right behind the update, on the caller's stream, instead of by
+        # the next step's forward on the side stream beside its first kernels
+        self.pack_after_update = os.environ.get("UNET_PACK_AFTER_UPDATE") is not None and hasattr(model, "pack_filters")
+        self._packed_size, self._packed_version = None, None
         self.stats_direct = hasattr(model, "_run_forward_loss") and os.environ.get("UNET_NO_STATS_DIRECT") is None
         self._lanes, self._gbufs, self._gptrs = None, [], []
         self.cur_epoch = 0
@@ -113,7 +117,9 @@ class Trainer:
         for k, b in enumerate(mine):
             x, t = self.source(cur_data_index + b)
             # the parameters only change at the end of the step (train.cpp:765): this rank's micro-steps 2.. reuse the filter packs of its first
-            kw = {"packs_current": True} if (self.packs_reuse and k > 0) else {}
+            packed = self._packed_size == tuple(x.shape[2:]) and self._packed_version == getattr(m, "_params_version", None)
+            kw = {"packs_current": True} if (self.packs_reuse and (k > 0 or packed)) else {}
+            last_size = tuple(x.shape[2:])
             first_direct = k == 0 and self.stats_direct
             if first_direct:
                 kw["losses_out"] = self._stats
@@ -138,6 +144,9 @@ class Trainer:
             for w in works:
                 w.wait()
         m.optimizer.step(grad_scale=1.0 / p.batch_size, clip_norm=12.0)  # train.cpp:759-766
+        self._packed_size = None
+        if self.pack_after_update and mine and not lanes_on and m.pack_filters(last_size):
+            self._packed_size, self._packed_version = last_size, m._params_version
         if self.comm is not None and self.world_size > 1:
             for b in m.buffers():
                 self.comm.broadcast(b, 0, stream)
@@ -158,7 +167,9 @@ class Trainer:
         p, m = self.param, self.model
         x0, _ = self.source(cur_data_index + mine[0])
         if self._lanes is None:
-            self._lanes = [m.make_lane(x0.shape[2:]) for _ in range(self.in_flight)]
+            # UNET_LANE_CUS=<CUs per XCD and lane> (experiment): lane i on CUs [i * n, (i + 1) * n) of every XCD
+            n = int(os.environ.get("UNET_LANE_CUS", "0"))
+            self._lanes = [m.make_lane(x0.shape[2:], cu_range=(i * n, n) if n > 0 else None) for i in range(self.in_flight)]
         while len(self._gbufs) < len(mine):
             buf = m.flat_grads if not self._gbufs else torch.zeros_like(m.flat_grads)
             self._gbufs.append(buf)

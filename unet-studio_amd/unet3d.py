@@ -290,6 +290,17 @@ class UNet3d:
             self.num_batches_tracked += 1
         return outs
 
+    def pack_filters(self, size, with_dgrad=True):
+        """the filter packs of the workspace for volumes of `size`, made now on the current stream (unet_pack_filters); True when the
+        next forward at this size may be given packs_current"""
+        import ctypes
+        plan = self.plan_for(tuple(size))
+        ws = self._workspace(plan)
+        made = ctypes.c_int(0)
+        E.check(E.lib.unet_pack_filters(plan.handle, self._pp, ws.data_ptr(), 1 if with_dgrad else 0, ctypes.byref(made),
+                                        _stream_ptr(self._device)))
+        return bool(made.value)
+
     def _run_backward(self, plan, ws, grad_outs, grad_x=None, gp=None):
         """gp: pointer array of a gradient buffer other than flat_grads (grad_pointers), for micro-steps that run side by side"""
         pp, gp = self._pp, (gp if gp is not None else self._gp)
@@ -324,7 +335,7 @@ class UNet3d:
         assert flat.numel() == self.flat_grads.numel() and flat.dtype == torch.float32 and flat.device == self._device
         return E.ptr_array([flat.data_ptr() + 4 * self._offsets[i] for i in range(len(self._params))])
 
-    def make_lane(self, size):
+    def make_lane(self, size, cu_range=None):
         """What a micro-step needs for ITSELF to run beside another one of the same optimizer step: a stream, a plan (a plan owns the
         side stream and the events of its backward: two backwards on ONE plan at a time are not supported, include/unet_hip.h), a
         workspace and a loss scratch.  The reference runs the batch_size micro-steps of a step on as many threads as it has GPUs
@@ -332,7 +343,14 @@ class UNet3d:
         bound small levels under the other's bandwidth-bound large ones."""
         key = tuple(int(v) for v in size)
         plan = E.Plan(self.architecture, self.in_count, self.out_count, key, self._dtype, self._device.index or 0, self._impl)
-        return {"plan": plan, "stream": torch.cuda.Stream(self._device),
+        stream = torch.cuda.Stream(self._device)
+        if cu_range is not None:    # experiment: the lane (its stream and its plan's side stream) on CUs [first, first + count) of every XCD
+            import ctypes
+            h = ctypes.c_void_p()
+            E.check(E.lib.unet_stream_create_cu_range(self._device.index or 0, int(cu_range[0]), int(cu_range[1]), ctypes.byref(h)))
+            stream = torch.cuda.ExternalStream(h.value, device=self._device)
+            E.check(E.lib.unet_plan_side_cu_range(plan.handle, int(cu_range[0]), int(cu_range[1])))
+        return {"plan": plan, "stream": stream,
                 "ws": torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=self._device),
                 "loss": torch.empty(plan.loss_scratch_bytes, dtype=torch.uint8, device=self._device)}
 
