@@ -187,6 +187,21 @@ struct unet_plan {
         }
     }
 
+    // tensor t is read by fused heads only (bf16): see layout()
+    bool head_only(size_t t) const {
+        static const bool off = getenv("UNET_HEAD_VIEW") && getenv("UNET_HEAD_VIEW")[0] == '0';
+        if (off || dtype != UNET_DTYPE_BF16 || g.tensors[t].norm < 0 || g.tensors[t].C % 16) return false;
+        int readers = 0;
+        for (const Op& op : g.ops) {
+            if (op.kind == OP_NORM) continue;
+            for (int k = 0; k < op.nsrc; ++k) {
+                if (op.src[k] != (int)t) continue;
+                if (!(op.kind == OP_CONV && op.out_level >= 0 && op.nsrc == 1 && head_supported(op_geom_of(op), 1))) return false;
+                ++readers;
+            }
+        }
+        return readers > 0;
+    }
     void layout() {
         choose_polite();
         size_t off = 0;
@@ -206,7 +221,10 @@ struct unet_plan {
             // Activated copy act(norm(u)): one extra write + the consumers read it as is.  Measured on the 32->16 conv at
             // 128^3: transforming in the conv's staging loop costs +85 % of the kernel (VALU-bound, repeated for the
             // 2.5x halo re-reads), the separate 2-pass copy ~0.03 ms.  288 GB of HBM makes the extra tensor free.
-            if (impl == UNET_IMPL_AUTO && (g.tensors[i].norm >= 0 || g.tensors[i].act != ACT_NONE))
+            // ... except for a tensor whose only readers are fused heads (the decoder's last tensor at full resolution): the head kernels are
+            // bandwidth-bound element-wise passes that transform as they load, so the copy (read + write of 64 MB at 128^3) is never made.
+            // (UNET_HEAD_VIEW=0 keeps the copy.)
+            if (impl == UNET_IMPL_AUTO && (g.tensors[i].norm >= 0 || g.tensors[i].act != ACT_NONE) && !head_only(i))
                 a_off[i] = take((size_t)g.tensors[i].numel() * elsize);
         }
         n_stat.resize(g.norms.size()); n_coef.resize(g.norms.size());

@@ -775,9 +775,13 @@ template <typename T> __global__ void __launch_bounds__(256) k_wgrad_first(Wgrad
 
 // ---- the 1x1x1 heads (Conv3d(C, out_count, 1), unet.cpp:157-160), forward and fused backward ----------------------------------
 // Lanes = (voxel, 16-channel chunk) as in k_wgrad_head; the filter ([Cout][Cin] fp32, torch layout, no pack) sits in LDS.
-template <typename T> __device__ __forceinline__ void load_chunk16(const SrcDesc& src, bool plain, int64_t v, int c0, bool ok, float (&x)[16]) {
+// ss: LDS image {scale[Cin], shift[Cin]} of a viewed bf16 source (nullptr: plain source, or the scalar path below).  A viewed source
+// is the raw tensor of a norm layer whose activated copy was never written (the head is its only reader: engine.cpp, layout()):
+// two 16-B loads + the transform of view_ld (v * scale + shift, then the activation) in registers.
+template <typename T> __device__ __forceinline__ void load_chunk16(const SrcDesc& src, bool plain, int64_t v, int c0, bool ok, float (&x)[16],
+                                                                  const float* ss = nullptr, int Cin = 0) {
     if constexpr (sizeof(T) == 2) {
-        if (plain) {
+        if (plain || ss) {
             uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
             if (ok) {
                 const uint4* q = (const uint4*)((const bf16*)src.ptr + v * src.C + c0);
@@ -786,11 +790,29 @@ template <typename T> __device__ __forceinline__ void load_chunk16(const SrcDesc
             const unsigned w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
             for (int k = 0; k < 8; ++k) { x[2 * k] = __uint_as_float(w[k] << 16); x[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+            if (!plain) {
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 sc = *(const float4*)(ss + c0 + 4 * k4), sh = *(const float4*)(ss + Cin + c0 + 4 * k4);
+                    x[4 * k4] = act_f(x[4 * k4] * sc.x + sh.x, src.act); x[4 * k4 + 1] = act_f(x[4 * k4 + 1] * sc.y + sh.y, src.act);
+                    x[4 * k4 + 2] = act_f(x[4 * k4 + 2] * sc.z + sh.z, src.act); x[4 * k4 + 3] = act_f(x[4 * k4 + 3] * sc.w + sh.w, src.act);
+                }
+                if (!ok) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) x[k] = 0.f;
+                }
+            }
             return;
         }
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = ok ? view_ld<T>(src, v, c0 + k) : 0.f;
+}
+// the viewed bf16 source's {scale, shift} behind the filter in LDS (head kernels; the caller synchronizes)
+template <typename T> __device__ __forceinline__ const float* stage_view(const SrcDesc& src, float* sm_after_filter, int Cin) {
+    if (sizeof(T) != 2 || !src.scale) return nullptr;
+    for (int i = threadIdx.x; i < Cin; i += 256) { sm_after_filter[i] = src.scale[i]; sm_after_filter[Cin + i] = src.shift[i]; }
+    return sm_after_filter;
 }
 
 struct HeadArgs {
@@ -810,8 +832,9 @@ struct HeadArgs {
 };
 
 template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_fwd(HeadArgs a) {
-    extern __shared__ float sm[];      // [CO][Cin] (rows >= Cout zero)
+    extern __shared__ float sm[];      // [CO][Cin] (rows >= Cout zero), then {scale, shift}[Cin] of a viewed source
     for (int i = threadIdx.x; i < CO * a.Cin; i += 256) sm[i] = i < a.Cout * a.Cin ? a.w[i] : 0.f;
+    const float* ss = stage_view<T>(a.src, sm + CO * a.Cin, a.Cin);
     __syncthreads();
     const int nchunk = 1 << a.lc, chunk = threadIdx.x & (nchunk - 1), c0 = chunk * 16;
     const int64_t vstride = ((int64_t)gridDim.x * 256) >> a.lc;
@@ -823,7 +846,7 @@ template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_fwd(
     for (int64_t v0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> a.lc; v0 < ((a.S + 63) & ~(int64_t)63); v0 += vstride) {
         const bool ok = v0 < a.S;
         float x[16], o[CO];
-        load_chunk16<T>(a.src, plain, v0, c0, ok, x);
+        load_chunk16<T>(a.src, plain, v0, c0, ok, x, ss, a.Cin);
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
             const float4* wr = (const float4*)(sm + c * a.Cin + c0);
@@ -850,9 +873,10 @@ template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_fwd(
 
 // dL/dW, dL/db and dL/d(source) of a head in one pass over (source, dy): replaces gradient import + wgrad + dgrad
 template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_bwd(HeadArgs a) {
-    extern __shared__ float sm[];      // [CO][Cin] filter, later the wgrad reduction scratch
+    extern __shared__ float sm[];      // [CO][Cin] filter (+ {scale, shift}[Cin] of a viewed source), later the wgrad reduction scratch
     constexpr int NACC = CO * 16 + CO;
     for (int i = threadIdx.x; i < CO * a.Cin; i += 256) sm[i] = i < a.Cout * a.Cin ? a.w[i] : 0.f;
+    const float* ss = stage_view<T>(a.src, sm + CO * a.Cin, a.Cin);
     __syncthreads();
     const int nchunk = 1 << a.lc, chunk = threadIdx.x & (nchunk - 1), c0 = chunk * 16;
     const int64_t vstride = ((int64_t)gridDim.x * 256) >> a.lc;
@@ -863,7 +887,7 @@ template <typename T, int CO> __global__ void __launch_bounds__(256) k_head_bwd(
     // the next voxel's operands are requested before this voxel's 200 FMAs (a thread walks ~16 voxels; one load -> use round trip
     // per voxel left the level-0 head at 63 us for 184 MB)
     auto fetch = [&](int64_t v, float (&xo)[16], float (&dout)[CO]) {
-        load_chunk16<T>(a.src, plain, v, c0, true, xo);
+        load_chunk16<T>(a.src, plain, v, c0, true, xo, ss, a.Cin);
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
             dout[c] = 0.f;
@@ -1025,7 +1049,7 @@ void launch_head_fwd(int dtype, const ConvGeom& g, const SrcDesc& src, const flo
     int64_t items = ((a.S + 63) & ~(int64_t)63) << a.lc;
     int64_t nb = (items + 255) / 256;
     if (nb > 2048) nb = 2048;
-    UNET_DISPATCH(dtype, (head_launch<T>(false, CO, (int)nb, (size_t)CO * g.Cin * 4, a, s)));
+    UNET_DISPATCH(dtype, (head_launch<T>(false, CO, (int)nb, (size_t)(CO + 2) * g.Cin * 4, a, s)));
 }
 // reduce_stream (optional): the slab sum that finishes dW / db runs there instead of on `s` -- it feeds nothing on the caller's
 // chain; the CALLER orders reduce_stream after this launch (an event) and keeps `scratch` untouched until the reduce has run
@@ -1037,7 +1061,7 @@ void launch_head_bwd(int dtype, const ConvGeom& g, const SrcDesc& src, const flo
     a.slab = dw ? (float*)scratch : nullptr;
     const int CO = head_co(g.Cout);
     const int nb = wgrad_reg_blocks((a.S << a.lc) * 4);   // one (voxel, chunk) item per thread until 512 blocks are reached
-    const size_t l0 = (size_t)CO * g.Cin * 4, l1 = small_wgrad_lds_bytes(CO * 17, 1 << a.lc);
+    const size_t l0 = (size_t)(CO + 2) * g.Cin * 4, l1 = small_wgrad_lds_bytes(CO * 17, 1 << a.lc);
     UNET_DISPATCH(dtype, (head_launch<T>(true, CO, nb, l0 > l1 ? l0 : l1, a, s)));
     if (dw && !defer_reduce) slab_reduce2(a.slab, nb, (int64_t)g.Cin * g.Cout + g.Cout, dw, (int64_t)g.Cin * g.Cout, db, s);
 }
