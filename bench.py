@@ -88,6 +88,9 @@ def dominant_kernel(U, size, dtype_name, iters=20):
     return flops, sec
 
 
+os.environ.setdefault("UNET_OP_POLITE", "1")   # op-level weight-gradient launches in the configuration the train step uses (engine.cpp)
+
+
 def dominant_wgrad(U, size, dtype_name, cin=32, cout=16, iters=20):
     """The heaviest weight gradient of the step (decode0.0: dW of conv3d cin->cout 3x3x3 @ size^3) through
     unet_op_conv3d_bwd_weight: the wgrad kernel + its slab reduce, as a plan launches them."""

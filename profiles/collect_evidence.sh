@@ -1,8 +1,8 @@
-# everything DESIGN.md / the bench line cite for round 3, in one GPU call:  gpurun -- 'bash profiles/collect_r08_evidence.sh'
+# everything DESIGN.md / the bench line cite for round 3, in one GPU call:  gpurun -- 'bash profiles/collect_evidence.sh [tag]'
 set -x
 R=$GRAFT_REPO_ROOT
 cd $R
-T=r08
+T=${1:-r11}
 python bench.py --steps 50 --warmup 10 > gpurun_out/${T}_bench_full.json 2> gpurun_out/${T}_bench_full.err
 bash profiles/profile_step_clean.sh $T > /dev/null 2>&1
 python3 profiles/timeline.py gpurun_out/prof_${T}_clean/runc_kernel_trace.csv 2 400 > gpurun_out/${T}_timeline.txt 2>&1

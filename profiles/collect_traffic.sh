@@ -6,7 +6,7 @@
 # Run on the GPU box from the repo root.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
-export TMPDIR=/tmp
+export TMPDIR=/tmp UNET_OP_POLITE=1     # the weight gradient as the train step launches it (polite: engine.cpp, choose_polite)
 WHICH=${1:-conv}
 if [ "$WHICH" = wgrad ]; then NAME=wgrad_kernel_traffic; SCRIPT="$R/profiles/wgrad_kernel.py 32 16 128"; else NAME=dominant_kernel_traffic; SCRIPT="$R/profiles/dominant_kernel.py"; fi
 cd /tmp

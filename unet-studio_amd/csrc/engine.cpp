@@ -1625,8 +1625,11 @@ int unet_op_conv3d_bwd_weight(int dtype, int impl, const void* x, const void* dy
     OP_TRY({
         ConvGeom g = op_geom(cin, cout, D, H, W, ks, stride, false);
         SrcDesc sd; sd.ptr = x; sd.C = cin;
+        // UNET_OP_POLITE=1: the launch configuration the engine gives this layer's gradient on its side stream (one 4-wave block per
+        // CU, single (ca, cb) pairs) -- for micro-benchmarks and counter collection of the kernel as the train step runs it
+        static const bool op_polite = getenv("UNET_OP_POLITE") != nullptr;
         if (impl == UNET_IMPL_AUTO && mfma_wgrad_supported(dtype, g, &sd, 1))
-            launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream);
+            launch_mfma_conv_wgrad(g, &sd, 1, dy, dw, db, scratch, (hipStream_t)stream, false, op_polite ? 1 : 0);
         else if (impl == UNET_IMPL_AUTO && conv_first_wgrad_mfma_supported(dtype, g, &sd, 1))
             launch_conv_first_wgrad_mfma(g, &sd, dy, dw, db, scratch, (hipStream_t)stream);
         else if (impl == UNET_IMPL_AUTO && wgrad_f32_mfma_supported(dtype, g, &sd, 1))
