@@ -197,7 +197,9 @@ def test_conv3d_fused_prologue_epilogue(case, dt, impl):
                                   # MFMA conv_trans (Cin % 32 == 0): every tile configuration, ragged edges
                                   (64, 32, (3, 5, 19)), (32, 32, (4, 4, 4)), (128, 64, (2, 3, 2)), (32, 48, (5, 9, 7)),
                                   # output-stationary conv_trans wgrad (coarse side 4^3 above, 8^3 here: 4 tiles along z per block)
-                                  (32, 48, (8, 8, 8))])
+                                  (32, 48, (8, 8, 8)),
+                                  # conv_trans dgrad with 32-channel chunks (Cout % 32 == 0 on coarse grids of 8^3 or less): both tiles
+                                  (64, 64, (5, 6, 7)), (32, 96, (8, 8, 8)), (256, 256, (4, 4, 4))])
 def test_convt_ops(case, dt):
     cin, cout, (D, H, W) = case
     l = O.lib()

@@ -109,7 +109,9 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, __bf16* _
         case PK_CONV_DGRAD:
             if (CK == 32) pack_unit_t<32, 27, PK_CONV_DGRAD>(w, out, unit, Co, A, B, lds); else pack_unit_t<16, 27, PK_CONV_DGRAD>(w, out, unit, Co, A, B, lds);
             break;
-        case PK_CONVT_DGRAD: pack_unit_t<16, 8, PK_CONVT_DGRAD>(w, out, unit, Co, A, B, lds); break;
+        case PK_CONVT_DGRAD:
+            if (CK == 32) pack_unit_t<32, 8, PK_CONVT_DGRAD>(w, out, unit, Co, A, B, lds); else pack_unit_t<16, 8, PK_CONVT_DGRAD>(w, out, unit, Co, A, B, lds);
+            break;
         case PK_CONVT_FWD: pack_unit_t<32, 1, PK_CONVT_FWD>(w, out, unit, Co, A, B, lds); break;
         default: pack_unit_t<32, 8, PK_CONV_S2_DGRAD>(w, out, unit, Co, A, B, lds); break;
     }
@@ -1150,6 +1152,17 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
 template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> static int launch_nt(const MfmaConvArgs& a, hipStream_t s) {
     int ntt = a.g.Cout / 16;
     if constexpr (SC) {   // scatter kinds always have ntt % 4 == 0 (rows = 8 * C, C % 16 == 0)
+        // small volumes (the 4^3 / 8^3 levels: 1..8 tiles): fewer row tiles per block, so that more blocks stream the filter
+        // (UNET_SC_NT=4 restores four row tiles per block everywhere)
+        static const int sc_nt = getenv("UNET_SC_NT") ? atoi(getenv("UNET_SC_NT")) : 0;
+        int tiles = ((a.g.Wo + BX - 1) / BX) * ((a.g.Ho + BY - 1) / BY) * ((a.g.Do + BZ - 1) / BZ);
+        int nt = 4;
+        if constexpr (BX <= 8) {
+            while (nt > 1 && (int64_t)tiles * (ntt / nt) < 256) nt >>= 1;
+            if (sc_nt > 0) nt = sc_nt;
+            if (nt == 1) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, true>(a, s);
+            if (nt == 2) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, true>(a, s);
+        }
         return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, true>(a, s);
     } else {
         // row tiles per block: as many as divide the row count, fewer when the grid would not fill the 256 CUs
@@ -1216,7 +1229,17 @@ static int launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 only (
     else if (a.g.Wo > 4) return launch_nt<2, 3, 1, 2, 4, 8, 16, false>(a, s);
     else return launch_nt<2, 3, 1, 4, 4, 4, 16, false>(a, s);
 }
-static void launch_s2k2(const MfmaConvArgs& a, hipStream_t s) {   // conv_trans dgrad, CK 16
+// conv_trans dgrad onto 8^3 voxels or fewer: 32-channel chunks (half as many pipeline stages; the 64-voxel tile's halo is 49 KB)
+static int convt_dgrad_ck(int cout_fwd, int coarseW) {
+    static const bool off = getenv("UNET_CONVT_DGRAD_CK16") != nullptr;
+    return (!off && cout_fwd % 32 == 0 && coarseW <= 8) ? 32 : 16;
+}
+static void launch_s2k2(const MfmaConvArgs& a, hipStream_t s) {   // conv_trans dgrad, CK 16 (small volumes: 32)
+    if (convt_dgrad_ck(a.g.Cin, a.g.Wo) == 32) {
+        if (a.g.Wo > 4) launch_nt<2, 2, 0, 2, 4, 8, 32, false>(a, s);
+        else launch_nt<2, 2, 0, 4, 4, 4, 32, false>(a, s);
+        return;
+    }
     if (a.g.Wo >= 12) launch_nt<2, 2, 0, 2, 4, 16, 16, false>(a, s);
     else if (a.g.Wo > 4) launch_nt<2, 2, 0, 4, 8, 8, 16, false>(a, s);
     else launch_nt<2, 2, 0, 4, 4, 4, 16, false>(a, s);
@@ -1328,14 +1351,14 @@ bool mfma_convt_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int 
     return dtype == 1 && chan_ok(g, src, nsrc) && g.Cin % 32 == 0;
 }
 size_t mfma_convt_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cin, 8 * g.Cout, 32, 1); }
-size_t mfma_convt_dgrad_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cout, g.Cin, 16, 8); }
+size_t mfma_convt_dgrad_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cout, g.Cin, convt_dgrad_ck(g.Cout, g.W), 8); }
 void launch_mfma_pack_convt_w(const float* w, void* w_fwd, void* w_dgrad, const ConvGeom& g, hipStream_t s) {
     if (w_fwd) run_pack(w, w_fwd, g.Cin, 8 * g.Cout, 32, 1, PK_CONVT_FWD, g.Cin, g.Cout, s);
-    if (w_dgrad) run_pack(w, w_dgrad, g.Cout, g.Cin, 16, 8, PK_CONVT_DGRAD, g.Cin, g.Cout, s);
+    if (w_dgrad) run_pack(w, w_dgrad, g.Cout, g.Cin, convt_dgrad_ck(g.Cout, g.W), 8, PK_CONVT_DGRAD, g.Cin, g.Cout, s);
 }
 int mfma_convt_pack_jobs(const ConvGeom& g, PackJob* out) {
     out[0] = make_job(g.Cin, 8 * g.Cout, 32, 1, PK_CONVT_FWD, g.Cin, g.Cout);
-    out[1] = make_job(g.Cout, g.Cin, 16, 8, PK_CONVT_DGRAD, g.Cin, g.Cout);
+    out[1] = make_job(g.Cout, g.Cin, convt_dgrad_ck(g.Cout, g.W), 8, PK_CONVT_DGRAD, g.Cin, g.Cout);
     return 2;
 }
 void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s) {
