@@ -533,8 +533,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
 //   3. sums the 4 partial accumulators through LDS; wave w finishes m-tile w (bias, bf16, statistics, accumulate).
 // Same LDS tile layout (64-B voxels, swizzled), filter pack, arguments and epilogue semantics as k_mfma_conv_p<1,3,1,..,32,1,false>.
 // ------------------------------------------------------------------------------------------------
+// BNS (dgrad only, as k_mfma_conv_z16<.., true>): the destination is the view of a norm layer read by this conv alone, so its gradient is
+// complete when this kernel has written it: the epilogue also reads the RAW tensor at the voxels it stores and leaves the norm backward's
+// statistics {sum dv, sum dv * xhat}, dv = dL/d(view) * act'(u * scale + shift), as one row per tile in a.bn_partial -- the separate
+// k_norm_bwd_stats8 launch (5-6 us of the caller's stream per layer at these levels) is not needed.
 constexpr int SMALL_QS = 8;
-template <int BZ, int BY, int BX, int OCC>
+template <int BZ, int BY, int BX, int OCC, bool BNS = false>
 __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
     constexpr int HZ = BZ + 2, HY = BY + 2, HX = BX + 2, HXP = (HX + 3) / 4 * 4;
     constexpr int TXM = BX < 16 ? BX : 16, TYM = 16 / TXM, RG = BY / TYM;
@@ -680,11 +684,23 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
             o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
             *p = o;
             const float r0 = bf_lo(o.x), r1 = bf_hi(o.x), r2 = bf_lo(o.y), r3 = bf_hi(o.y);
-            s1[0] = r0; s1[1] = r1; s1[2] = r2; s1[3] = r3;
-            s2[0] = r0 * r0; s2[1] = r1 * r1; s2[2] = r2 * r2; s2[3] = r3 * r3;
+            if constexpr (BNS) {
+                const uint2 ur = *(const uint2*)((const char*)a.bn_u + (vox * a.bn_C + c) * 2);
+                const float uu[4] = {bf_lo(ur.x), bf_hi(ur.x), bf_lo(ur.y), bf_hi(ur.y)}, rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mean = a.bn_stat[c + r], rstd = a.bn_stat[a.bn_C + c + r];
+                    const float dv = rr[r] * act_d(fmaf(uu[r], a.bn_stat[2 * a.bn_C + c + r], a.bn_stat[3 * a.bn_C + c + r]), a.bn_act);
+                    s1[r] = dv; s2[r] = dv * ((uu[r] - mean) * rstd);
+                }
+            } else {
+                s1[0] = r0; s1[1] = r1; s1[2] = r2; s1[3] = r3;
+                s2[0] = r0 * r0; s2[1] = r1 * r1; s2[2] = r2 * r2; s2[3] = r3 * r3;
+            }
         }
     }
-    if (a.stats) {   // statistics of the values as stored: one partial row per tile
+    float* const srows = BNS ? a.bn_partial : a.stats;
+    if (srows) {   // statistics of the values as stored (BNS: the norm backward's): one partial row per tile
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -698,8 +714,8 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
             float u = 0.f, v = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { u += red[(w * 16 + tid) * 2]; v += red[(w * 16 + tid) * 2 + 1]; }
-            a.stats[((size_t)bid * g.Cout + nt0 * 16 + tid) * 2 + 0] = u;
-            a.stats[((size_t)bid * g.Cout + nt0 * 16 + tid) * 2 + 1] = v;
+            srows[((size_t)bid * g.Cout + nt0 * 16 + tid) * 2 + 0] = u;
+            srows[((size_t)bid * g.Cout + nt0 * 16 + tid) * 2 + 1] = v;
         }
     }
 }
@@ -1208,6 +1224,14 @@ template <int BZ, int BY, int BX> static int launch_small(const MfmaConvArgs& a0
     set_max_lds_once(attr2_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 2>, 80 * 1024);
     const int tiles = a.tiles_x * a.tiles_y * a.tiles_z;
     dim3 grid((unsigned)tiles, (unsigned)(a.g.Cout / 16));
+    if (a.bn_partial) {   // dgrad with the norm backward's statistics in the epilogue
+        static std::atomic<uint64_t> attr3_done{0}, attr4_done{0};
+        set_max_lds_once(attr3_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 1, true>, (int)(SMALL_QS * tile_b));
+        set_max_lds_once(attr4_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 2, true>, 80 * 1024);
+        if (lds <= 80 * 1024) k_mfma_conv_small<BZ, BY, BX, 2, true><<<grid, 256, lds, s>>>(a);
+        else k_mfma_conv_small<BZ, BY, BX, 1, true><<<grid, 256, lds, s>>>(a);
+        return tiles;
+    }
     if (lds <= 80 * 1024) k_mfma_conv_small<BZ, BY, BX, 2><<<grid, 256, lds, s>>>(a);   // two blocks per CU
     else k_mfma_conv_small<BZ, BY, BX, 1><<<grid, 256, lds, s>>>(a);
     return tiles;
@@ -1336,6 +1360,13 @@ int launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma
         if (bn && !no_bn && ndst == 1 && dst[0].ptr && !dst[0].accumulate && bn->C == g.Cin && pick_ck(g.Cout, true) == 16 && conv_z16_applies(a)) {
             a.bn_u = bn->u; a.bn_stat = bn->stat; a.bn_partial = bn->partial; a.bn_act = bn->act; a.bn_C = bn->C;
             return launch_conv_z16(a, s);
+        }
+        // ... and of k_mfma_conv_small (the 16^3 and smaller levels; the sliding-window kernels need Cin == 32 and never take these)
+        static const bool no_bn_small = getenv("UNET_NO_DGRAD_BNSTATS_SMALL") != nullptr;
+        if (bn && !no_bn && !no_bn_small && ndst == 1 && dst[0].ptr && !dst[0].accumulate && bn->C == g.Cin && pick_ck(g.Cout, true) == 32 &&
+            a.g.Cin != 32 && small_s1k3(a.g, 32)) {
+            a.bn_u = bn->u; a.bn_stat = bn->stat; a.bn_partial = bn->partial; a.bn_act = bn->act; a.bn_C = bn->C;
+            return launch_s1k3(a, 32, s);
         }
         launch_s1k3(a, pick_ck(g.Cout, true), s);
     } else {
