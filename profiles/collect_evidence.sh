@@ -26,3 +26,10 @@ for f in 1 2; do UNET_MICRO_IN_FLIGHT=$f python bench.py --steps 10 --warmup 4 -
 python profiles/forward_only.py 128 > gpurun_out/${T}_forward_only.json 2>/dev/null
 python profiles/bench_evaluate.py > gpurun_out/${T}_bench_evaluate.json 2>/dev/null
 tail -c 1500 gpurun_out/${T}_bench_full.json
+# soak: 300 steps, loss and memory every 25 (profiles/soak_train.py)
+python profiles/soak_train.py > gpurun_out/${T}_soak.txt 2>&1
+# how much longer the caller's stream's kernels take beside the side stream than alone (profiles/stretch.py)
+cd /tmp && export TMPDIR=/tmp
+UNET_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_${T}_solo -o runc -- python3 $R/bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-profile --no-kernels --batch 0 > $R/gpurun_out/prof_${T}_solo.log 2>&1
+cd $R
+python3 profiles/stretch.py gpurun_out/prof_${T}_clean/runc_kernel_trace.csv gpurun_out/prof_${T}_solo/runc_kernel_trace.csv 8 60 > gpurun_out/${T}_stretch.txt 2>&1
