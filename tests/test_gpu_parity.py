@@ -777,6 +777,21 @@ def test_norm_backward_statistics_in_the_small_volume_dgrad_epilogue_match_the_s
     assert np.abs(g1 - g0).max() <= 2e-2 * np.abs(g0).max()
 
 
+def test_weight_gradients_in_the_polite_launch_configuration():
+    """The engine launches the weight gradients of its side stream "politely" (engine.cpp: choose_polite -- 4-wave blocks, one per CU,
+    the sliding-window kernel in (2 x 1) / (1 x 2) tile pairs of 4 rows instead of the 8-wave pair blocks): UNET_OP_POLITE=1 gives the
+    op-level entry point the same configuration, and every conv case of this file must still match the oracle.  The switch is read
+    once per process: the cases run again in a child."""
+    import subprocess
+    import sys
+    env = dict(os.environ, UNET_OP_POLITE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                          "-p", "no:cacheprovider", "-k", "test_conv3d_ops and bf16"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
 def test_first_conv_weight_gradient_with_the_norm_backward_pass_fused_equals_the_separate_pass(tmp_path):
     """dL/d(raw output) of the network's first conv is read by nothing but its weight gradient, so that kernel applies the norm
     backward's element-wise pass while it stages its tiles (NormBwdFuse, engine.cpp) instead of reading a tensor a separate pass wrote;

@@ -394,7 +394,13 @@ static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c, int polite = 0) {
     // at 32^3 a 2x2-pair block leaves 128 blocks for the chip (4 footprint columns x 8 segments x 4 pair groups); single pairs give 512
     // (step 3.22 -> 3.19 ms; at 64^3 no difference).  UNET_WZ_P11 = voxel count at or below which single pairs are used.
     static const int p11_vox = getenv("UNET_WZ_P11") ? atoi(getenv("UNET_WZ_P11")) : 32768;
-    if ((p11_vox > 0 && (int64_t)g.D * g.H * g.W <= (int64_t)p11_vox) || polite) { c.pa = 1; c.pb = 1; c.wk = 4; }   // polite: 4-wave blocks
+    if (p11_vox > 0 && (int64_t)g.D * g.H * g.W <= (int64_t)p11_vox) { c.pa = 1; c.pb = 1; c.wk = 4; }
+    else if (polite) {   // 4-wave blocks: a pair of tiles on one side where the channels allow it (one read of the other side serves both), 4 rows
+        static const bool pairs = getenv("UNET_WZ_POLITE_SINGLE") == nullptr;
+        if (pairs && cat % 2 == 0) { c.pa = 2; c.pb = 1; c.wk = 2; }
+        else if (pairs && cbt % 2 == 0) { c.pa = 1; c.pb = 2; c.wk = 2; }
+        else { c.pa = 1; c.pb = 1; c.wk = 4; }
+    }
     c.by = 2 * c.wk;
     c.cols_x = (g.W + c.bx - 1) / c.bx; c.cols_y = (g.H + c.by - 1) / c.by;
     c.gy = (cat / c.pa) * (cbt / c.pb);
@@ -466,7 +472,9 @@ int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const v
     a.cols_x = c.cols_x; a.cols_y = c.cols_y; a.nseg = c.nseg; a.zlen = c.zlen;
     static const bool noslab = getenv("UNET_WZ_NOSLAB") != nullptr;   // timing experiment only (results are wrong): skip the slab stores
     if (noslab) a.nseg = -c.nseg;
-    if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s, polite);
+    if (c.wk == 2 && c.pa == 2 && c.pb == 1) launch_wz<32, 2, 2, 1>(a, c, s, polite);
+    else if (c.wk == 2 && c.pa == 1 && c.pb == 2) launch_wz<32, 2, 1, 2>(a, c, s, polite);
+    else if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s, polite);
     else if (c.pa == 2) launch_wz<32, 4, 2, 1>(a, c, s, polite);
     else if (c.pb == 2) launch_wz<32, 4, 1, 2>(a, c, s, polite);
     else launch_wz<32, 4, 1, 1>(a, c, s, polite);
