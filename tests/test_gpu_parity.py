@@ -64,6 +64,8 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     # output-stationary wgrad that adds straight into the gradient (tile side 4^3 / 8^3: no slab, no reduce): stride 2 with an 8^3
     # output from an even and from an odd input (4 tiles along z per block), stride 1 at 8^3 with several (ca, cb) pairs
     (32, 32, (16, 16, 16), 3, 2), (16, 32, (15, 15, 15), 3, 2), (48, 32, (8, 8, 8), 3, 1),
+    # stride-2 forward with 32-channel chunks (outputs of 8^3 voxels or fewer): eight and four chunks, both tiles, several row tiles
+    (256, 64, (8, 8, 8), 3, 2), (128, 48, (16, 16, 16), 3, 2), (96, 32, (13, 12, 15), 3, 2),
     # register-accumulating small wgrads: first conv (Cin = 1; W % 4 != 0 falls back to the row kernel) and 1x1x1 heads
     (1, 8, (6, 5, 8), 3, 1), (1, 16, (5, 6, 7), 3, 1), (1, 32, (17, 9, 16), 3, 1), (64, 6, (4, 5, 6), 1, 1), (256, 6, (3, 4, 5), 1, 1),
     (32, 3, (5, 6, 7), 1, 1), (16, 8, (33, 8, 9), 1, 1),

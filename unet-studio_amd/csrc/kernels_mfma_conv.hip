@@ -1140,7 +1140,8 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
     constexpr size_t tile_b = (size_t)((BZ - 1) * S + KD) * ((BY - 1) * S + KD) * HXP * VS;
     constexpr size_t lds = tile_b + (KSTEPS * NT <= 32 ? (size_t)KSTEPS * NT * 1024 : 0);
     static_assert(tile_b >= NW * NT * 16 * 2 * 4, "stats scratch must fit the tile buffer");
-    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    // two blocks per CU, except the stride-2 forward of the small levels with 32-channel chunks (16-128 blocks in all: one per CU)
+    static_assert(lds <= 80 * 1024 || (S == 2 && KD == 3 && CK == 32 && lds <= 128 * 1024), "LDS per block");
     static std::atomic<uint64_t> attr_done{0};
     set_max_lds_once(attr_done, (const void*)k_mfma_conv_p<S, KD, PAD, BZ, BY, BX, CK, NT, SC, NW, false>, (int)lds);
     // persistent grid: at most ~2 blocks per CU in total (256 CUs), tiles strided over them
@@ -1248,7 +1249,13 @@ static int launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
     else { if (CK == 32) return launch_nt<1, 3, 1, 4, 4, 4, 32, false>(a, s); else return launch_nt<1, 3, 1, 4, 4, 4, 16, false>(a, s); }
 }
 static Tile tile_s2k3(int Wo) { return Wo >= 12 ? Tile{2, 4, 16} : (Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4}); }
-static int launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 only (halo of a stride-2 tile is 8x the output tile)
+// stride-2 forward onto 8^3 voxels or fewer: 32-channel chunks (half as many pipeline stages; the 64-voxel tile's halo is 70 KB)
+static bool s2_fwd_ck32(const ConvGeom& g) {
+    static const bool off = getenv("UNET_S2_FWD_CK16") != nullptr;
+    return !off && g.stride == 2 && g.ks == 3 && g.Cin % 32 == 0 && g.Wo <= 8;
+}
+static int launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 (halo of a stride-2 tile is 8x the output tile); small volumes: 32
+    if (s2_fwd_ck32(a.g)) return a.g.Wo > 4 ? launch_nt<2, 3, 1, 2, 4, 8, 32, false>(a, s) : launch_nt<2, 3, 1, 4, 4, 4, 32, false>(a, s);
     if (a.g.Wo >= 12) return launch_nt<2, 3, 1, 2, 4, 16, 16, false>(a, s);
     else if (a.g.Wo > 4) return launch_nt<2, 3, 1, 2, 4, 8, 16, false>(a, s);
     else return launch_nt<2, 3, 1, 4, 4, 4, 16, false>(a, s);
@@ -1305,7 +1312,7 @@ static void set_dst(MfmaConvArgs& a, const DstGrad* dst, int ndst) {
 bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc) {
     return dtype == 1 && g.ks == 3 && (g.stride == 1 || g.stride == 2) && chan_ok(g, src, nsrc);
 }
-static int fwd_ck(const ConvGeom& g) { return g.stride == 1 ? pick_ck(g.Cin, true) : 16; }
+static int fwd_ck(const ConvGeom& g) { return g.stride == 1 ? pick_ck(g.Cin, true) : (s2_fwd_ck32(g) ? 32 : 16); }
 size_t mfma_conv_w_bytes(const ConvGeom& g) { return pack_bytes(g.Cin, g.Cout, fwd_ck(g), 27); }
 size_t mfma_conv_dgrad_w_bytes(const ConvGeom& g) {
     if (g.stride == 1) return pack_bytes(g.Cout, g.Cin, pick_ck(g.Cout, true), 27);
