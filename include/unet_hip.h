@@ -109,7 +109,8 @@ int unet_forward(const unet_plan* plan, const float* const* params, float* const
 
 /* backward of the last mode-1 forward on this workspace.  grad_outs: fp32 dL/d(outs[l]) or NULL (= no
  * loss on that level).  grad_params: fp32, parameters() order, ACCUMULATED (+=) as .grad is across the
- * batch_size micro-steps of one optimizer step (train.cpp:604-606,706).  grad_x: optional fp32 dL/dx.
+ * batch_size micro-steps of one optimizer step (train.cpp:604-606,706).  grad_x: must be NULL (the reference never asks for
+ * dL/dx -- the input is a leaf without requires_grad, train.cpp:619-628 -- and the engine does not compute it; non-NULL is an error).
  * The parameter-gradient kernels run on a side stream the plan owns, forked from and joined back into `stream`
  * before the call returns its work to the caller: stream order is all a caller needs, but two host threads must
  * not run unet_backward on the SAME plan concurrently (the reference trains one model per thread, train.cpp:573-579;

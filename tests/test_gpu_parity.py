@@ -922,6 +922,20 @@ def _in_flight_steps(ma, ta, mb, tb):
     assert float(ma.flat_grads.abs().max()) == 0.0 and all(float(g.abs().max()) == 0.0 for g in ta._gbufs)   # zero_grad reached every buffer
 
 
+def test_backward_refuses_a_gradient_buffer_for_the_input():
+    """dL/dx is not computed (the reference's input is a leaf without requires_grad, train.cpp:619-628): a non-NULL grad_x is an error with
+    a message, not a write through a buffer the plan never laid out"""
+    m = U.UNet3d(1, 4, ARCH_RESUME, device=DEV, dtype="bf16", seed=0)
+    x, t = U.SyntheticVolumes(1, 4, (16, 16, 16), DEV, cache=1)(0)
+    plan = m.plan_for(x.shape[2:]); ws = m._workspace(plan)
+    outs, losses, gouts = m._run_forward_loss(plan, ws, x, t, True, True, True, 0)
+    with pytest.raises(U.UNetError, match="grad_x"):
+        m._run_backward(plan, ws, gouts, grad_x=torch.empty_like(x))
+    m._run_backward(plan, ws, gouts)
+    torch.cuda.synchronize()
+    assert float(m.flat_grads.abs().max()) > 0
+
+
 def test_sum_buffers_is_the_sequential_accumulation():
     """unet_sum_buffers (include/unet_hip.h): ((b0 + b1) + b2) + ... in fp32, inputs cleared on request, odd tail, argument checks"""
     n = 4 * 1000 + 3

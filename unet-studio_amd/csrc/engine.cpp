@@ -566,7 +566,9 @@ struct Exec {
                         int rows = launch_conv_first_mfma(cg, sd, params[op.weight], params[op.bias], tptr(op.dst),
                                                           want_stats ? partial() : nullptr, s);
                         if (want_stats) fused_blocks[T.norm] = rows;
-                        if (mode == 1 && !packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
+                        // the fp32 [tap][cin][cout] copies are read by the direct dgrad only: not made when the input needs no gradient
+                        if (mode == 1 && !packs_current && g.tensors[op.src[0]].needs_grad)
+                            launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                     } else if (op.kind == OP_CONV && p.impl == UNET_IMPL_AUTO && op.out_level < 0 &&
                                conv_first_f32_mfma_supported(p.dtype, cg, sd, op.nsrc)) {
                         // fp32 engine, Cin = 1: the first conv on the fp32 matrix cores (filter read in torch layout), statistics in its epilogue
@@ -1125,6 +1127,7 @@ int unet_backward(const unet_plan* p, const float* const* params, const float* c
                   float* grad_x, void* workspace, void* stream) {
     try {
         if (!p || !params || !grad_params || !workspace) throw std::runtime_error("unet_backward: null argument");
+        if (grad_x) throw std::runtime_error("unet_backward: grad_x must be NULL -- dL/dx is not computed (the input carries no gradient, as in train.cpp:619-628)");
         DeviceGuard dg(p->device);
         Exec ex(*p, workspace, stream);
         ex.backward(params, grad_outs, grad_params, grad_x);
@@ -1138,6 +1141,7 @@ int unet_backward_part(const unet_plan* p, const float* const* params, const flo
     try {
         if (!p || !params || !grad_params || !workspace) throw std::runtime_error("unet_backward_part: null argument");
         if (op_lo < 0 || op_hi < op_lo) throw std::runtime_error("unet_backward_part: invalid op range");
+        if (grad_x) throw std::runtime_error("unet_backward_part: grad_x must be NULL -- dL/dx is not computed");
         DeviceGuard dg(p->device);
         Exec ex(*p, workspace, stream);
         ex.backward(params, grad_outs, grad_params, grad_x, op_hi, op_lo);
