@@ -80,6 +80,11 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     # sliding window for a single 16-channel chunk (bf16; forward Cin = 16, dgrad Cout = 16; W >= 12, D >= 8): one and two row tiles,
     # ragged footprints, z segments of unequal length
     (16, 16, (11, 9, 19), 3, 1), (16, 32, (10, 17, 33), 3, 1), (32, 16, (9, 10, 18), 3, 1), (16, 16, (37, 8, 16), 3, 1),
+    # stride-2 sliding-window kernels (kernels_mfma_s2.hip; bf16, output >= 16 wide, >= 4 deep): forward with 16- and 32-channel planes and
+    # 1 / 2 / 4 row tiles per block, dgrad with 32 and 64 dy channels and 1..3 row-tile blocks, odd input sizes (last fine plane / row /
+    # voxel without a partner), ragged footprints, z segments of unequal length; Cin 48 / Cout 16 fall back to the halo-tile kernel
+    (16, 32, (16, 20, 40), 3, 2), (32, 64, (9, 13, 35), 3, 2), (16, 16, (8, 8, 32), 3, 2), (32, 48, (11, 10, 33), 3, 2),
+    (16, 64, (12, 9, 38), 3, 2), (48, 32, (8, 12, 32), 3, 2), (32, 32, (37, 7, 31), 3, 2),
     # fp32 matrix-core conv (fp32 engine, volumes >= 4096 voxels): NT 1 / 2, ragged tile edges in z, y and x, 8-channel chunk tail
     (16, 16, (16, 16, 32), 3, 1), (32, 64, (17, 19, 21), 3, 1), (24, 48, (9, 23, 22), 3, 1), (64, 32, (18, 17, 16), 3, 1),
 ]
@@ -201,7 +206,11 @@ def test_conv3d_fused_prologue_epilogue(case, dt, impl):
                                   # output-stationary conv_trans wgrad (coarse side 4^3 above, 8^3 here: 4 tiles along z per block)
                                   (32, 48, (8, 8, 8)),
                                   # conv_trans dgrad with 32-channel chunks (Cout % 32 == 0 on coarse grids of 8^3 or less): both tiles
-                                  (64, 64, (5, 6, 7)), (32, 96, (8, 8, 8)), (256, 256, (4, 4, 4))])
+                                  (64, 64, (5, 6, 7)), (32, 96, (8, 8, 8)), (256, 256, (4, 4, 4)),
+                                  # sliding-window conv_trans kernels (kernels_mfma_s2.hip; coarse grid >= 16 wide, >= 4 deep): forward with 1 / 2 / 4
+                                  # k-steps and 1..4 row-tile blocks, dgrad with 16- and 32-channel planes and 2 / 4 row tiles per block, ragged edges
+                                  (32, 16, (4, 6, 16)), (64, 32, (5, 9, 19)), (128, 64, (4, 4, 16)), (32, 48, (6, 7, 17)), (64, 16, (7, 5, 20)),
+                                  (32, 32, (9, 4, 18))])
 def test_convt_ops(case, dt):
     cin, cout, (D, H, W) = case
     l = O.lib()
@@ -777,6 +786,25 @@ def test_norm_backward_statistics_in_the_small_volume_dgrad_epilogue_match_the_s
     for nm in ("decode2.1.weight", "decode2.1.bias"):
         assert np.abs(a1[nm] - a0[nm]).max() <= 1e-5 * np.abs(a0[nm]).max(), nm
     assert np.abs(g1 - g0).max() <= 2e-2 * np.abs(g0).max()
+
+
+def test_stride2_dgrad_statistics_epilogue_and_kernels_match_the_separate_pass_and_the_halo_tile_kernels(tmp_path):
+    """kernels_mfma_s2.hip in the network: the stride-2 conv reads the skip tensor, whose gradient has two writers -- its dgrad
+    (k_s2_scatter) ACCUMULATES into it (old values by LDS-DMA) and, as the last writer, leaves the norm backward's statistics
+    (UNET_NO_DGRAD_BNSTATS=1: separate k_norm_bwd_stats8 pass; UNET_NO_S2_KERNELS=1: the halo-tile kernels for every stride-2 /
+    conv_trans op).  At 64^3 the small U-Net's coarse level is 32^3: all four new kernels run.  Each variant in a fresh process (the
+    switches are read once).  The statistics agree to summation order, so encode0.4's norm parameters do; the rest sees bf16 rounding flips."""
+    g1, names = _grads_in_fresh_process(tmp_path, "s2_fused", 64, {})
+    g0, _ = _grads_in_fresh_process(tmp_path, "s2_separate", 64, {"UNET_NO_DGRAD_BNSTATS": "1"})
+    g2, _ = _grads_in_fresh_process(tmp_path, "s2_old", 64, {"UNET_NO_S2_KERNELS": "1"})
+    a1, a0, a2 = _by_name(g1, names), _by_name(g0, names), _by_name(g2, names)
+    assert np.abs(g1 - g0).max() > 0 and np.abs(g1 - g2).max() > 0, "the switches did not reach the engine"
+    for nm in ("encode0.4.weight", "encode0.4.bias"):      # fp32 sums over 64^3 voxels with cancellation, grouped differently: measured 7e-5
+        assert np.abs(a1[nm] - a0[nm]).max() <= 5e-4 * np.abs(a0[nm]).max(), nm
+    assert np.abs(g1 - g0).max() <= 5e-3 * np.abs(g0).max()
+    # against the halo-tile kernels: same arithmetic in another summation order (fp32 accumulators, then bf16 roundings downstream)
+    for nm in a2:
+        assert np.abs(a1[nm] - a2[nm]).max() <= 2e-2 * max(np.abs(a2[nm]).max(), 1e-3 * np.abs(g2).max()), nm
 
 
 def test_weight_gradients_in_the_polite_launch_configuration():

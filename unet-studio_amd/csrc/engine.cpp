@@ -80,6 +80,7 @@ struct unet_plan {
     std::vector<size_t> w_fwd, w_dgrad;      // per op (conv / conv_trans): packed fp32 weights
     std::vector<size_t> wm_fwd, wm_dgrad;    // per op: MFMA fragment-order bf16 filters (SIZE_MAX: op not on the MFMA path)
     std::vector<int> n_consumers;            // per tensor: ops that read it
+    std::vector<int> first_consumer;         // per tensor: lowest op index that reads it (-1: none) -- in the backward its LAST gradient writer
     // norm-backward partial rows a dgrad epilogue left in a workspace's partial() for the tensor's view_backward, which may run in a later
     // unet_backward_part call on the same workspace (the bucketed backward must make the same choices as the whole one): workspace -> {tensor, rows}
     mutable std::mutex bn_mu;
@@ -118,7 +119,6 @@ struct unet_plan {
     // of the bytes): nothing reads them before the backward, which waits for ev_packd.  An inference forward packs [0, pack_fwd_blocks) only.
     int pack_split_op = 0;
     int64_t pack_split_blocks = 0, pack_fwd_blocks = 0;
-    mutable std::atomic<bool> dgrad_packs_in_flight{false};
     size_t head_off = 0;                     // scratch of the fused head backward (stays on the main stream)
     std::vector<size_t> head_op_off;         // per op: a head's own slab region (its reduce runs on the side stream, later) or SIZE_MAX
 
@@ -209,10 +209,11 @@ struct unet_plan {
         t_off.assign(g.tensors.size(), SIZE_MAX);
         g_off.assign(g.tensors.size(), SIZE_MAX);
         n_consumers.assign(g.tensors.size(), 0);
+        first_consumer.assign(g.tensors.size(), -1);
         for (size_t oi = 0; oi < g.ops.size(); ++oi) {
             const Op& op = g.ops[oi];
             for (int k = 0; k < op.nsrc && op.kind != OP_NORM; ++k)     // (a norm op names the tensor it normalises: not a reader of the view)
-                if (op.src[k] >= 0) ++n_consumers[op.src[k]];
+                if (op.src[k] >= 0) { ++n_consumers[op.src[k]]; if (first_consumer[op.src[k]] < 0) first_consumer[op.src[k]] = (int)oi; }
         }
         a_off.assign(g.tensors.size(), SIZE_MAX);
         for (size_t i = 0; i < g.tensors.size(); ++i) {
@@ -268,6 +269,10 @@ struct unet_plan {
                 if (mfma_conv_dgrad_supported(dtype, cg, sd, op.nsrc)) {
                     dgrad_mfma[i] = 1;
                     wm_dgrad[i] = take(mfma_conv_dgrad_w_bytes(cg));
+                    if (op.stride == 2) {      // norm-backward partial rows of the stride-2 dgrad's epilogue (kernels_mfma_s2.hip)
+                        size_t pb = (size_t)s2_conv_dgrad_rows_max() * op.cin * 2 * 4;
+                        if (pb > pmax) pmax = pb;
+                    }
                 }
             }
             if (op.kind == OP_CONVT && impl == UNET_IMPL_AUTO) {
@@ -499,7 +504,6 @@ struct Exec {
                         if (early) {
                             launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks, pack_grid);
                             HIP_OK(hipEventRecord(p.ev_packd, p.side));
-                            p.dgrad_packs_in_flight.store(true);
                         } else dgrad_deferred = true;
                     } else {
                         launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks, p.side);
@@ -526,7 +530,6 @@ struct Exec {
             HIP_OK(hipStreamWaitEvent(p.side, p.ev_deep, 0));
             launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks, pack_grid);
             HIP_OK(hipEventRecord(p.ev_packd, p.side));
-            p.dgrad_packs_in_flight.store(true);
         };
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
@@ -698,8 +701,11 @@ struct Exec {
     void backward(const float* const* params, const float* const* grad_outs, float* const* gparams, float* grad_x, int op_hi = 1 << 30,
                   int op_lo = 0) {
         const Graph& g = p.g;
-        // the dgrad filter packs of this step were launched on the side stream in the middle of the forward
-        if (p.dgrad_packs_in_flight.exchange(false)) HIP_OK(hipStreamWaitEvent(s, p.ev_packd, 0));
+        // the dgrad filter packs of this step were launched on the side stream in the middle of the forward.  The wait is unconditional:
+        // the packs belong to a (workspace, stream) pair but the event is the plan's, and with two workspaces interleaved
+        // (A.forward, B.forward, B.backward, A.backward) a consumed-once flag let A's backward run ahead of A's packs.  The event's latest
+        // record is behind every earlier pack on the side stream, and waiting on a never-recorded or completed event costs nothing.
+        if (p.side) HIP_OK(hipStreamWaitEvent(s, p.ev_packd, 0));
         std::vector<char> init(g.tensors.size(), 0);
         auto dst_of = [&](int t) {
             DstGrad d;
@@ -897,10 +903,10 @@ struct Exec {
                             const int ts = op.src[0];
                             const Tensor& Ts = g.tensors[ts];
                             BnBwdStats bn = {tptr(ts), Ts.norm >= 0 ? stat(Ts.norm) : nullptr, partial(), Ts.act, Ts.C};
-                            // (With several consumers the one with the lowest op index writes last -- accumulating -- and would see the complete
-                            // gradient; for the skip tensors that is the stride-2 scatter dgrad, where the epilogue was built and measured:
-                            // +25 us in the dgrad for -27 us of statistics pass, not kept.)
-                            const bool can = op.nsrc == 1 && Ts.norm >= 0 && p.n_consumers[ts] == 1 && p.dtype == UNET_DTYPE_BF16;
+                            // With several consumers the one with the lowest op index writes last -- accumulating -- and sees the complete
+                            // gradient: for the skip tensors that is the stride-2 conv, whose dgrad (k_s2_scatter) fetches the old gradient
+                            // and the raw tensor by LDS-DMA and has the epilogue too.  (Stride-1 kernels only take it when they WRITE.)
+                            const bool can = op.nsrc == 1 && Ts.norm >= 0 && p.first_consumer[ts] == i && p.dtype == UNET_DTYPE_BF16;
                             const int rows = launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s, can ? &bn : nullptr);
                             if (rows > 0) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending[ws] = {ts, rows}; }
                         }
@@ -1114,6 +1120,7 @@ int unet_forward(const unet_plan* p, const float* const* params, float* const* b
                  void* workspace, int mode, void* stream) {
     try {
         if (!p || !params || !x || !workspace) throw std::runtime_error("unet_forward: null argument");
+        if (mode & ~(1 | UNET_MODE_PACKS_CURRENT)) throw std::runtime_error("unet_forward: unknown mode bits (0 = eval, 1 = train, optionally | UNET_MODE_PACKS_CURRENT)");
         if (!p->g.buffers.empty() && !buffers) throw std::runtime_error("unet_forward: architecture has bnorm layers but buffers is null");
         DeviceGuard dg(p->device);
         Exec ex(*p, workspace, stream);
@@ -1333,7 +1340,8 @@ int unet_forward_loss_mode(const unet_plan* p, const float* const* params, float
                            const int64_t* target, int cost_mask, int collapse_before, float* const* grad_outs, float* losses_out,
                            void* loss_scratch, void* workspace, int mode, void* stream) {
     try {
-        if ((mode & 1) != 1) throw std::runtime_error("unet_forward_loss_mode: mode must be 1 (train), optionally | UNET_MODE_PACKS_CURRENT");
+        if ((mode & 1) != 1 || (mode & ~(1 | UNET_MODE_PACKS_CURRENT)))
+            throw std::runtime_error("unet_forward_loss_mode: mode must be 1 (train), optionally | UNET_MODE_PACKS_CURRENT");
         if (!p || !params || !x || !workspace || !outs) throw std::runtime_error("unet_forward_loss: null argument");
         if (!p->g.buffers.empty() && !buffers) throw std::runtime_error("unet_forward_loss: architecture has bnorm layers but buffers is null");
         LossRun lr(p, outs, target, cost_mask, collapse_before, grad_outs, losses_out, loss_scratch);
@@ -1498,10 +1506,10 @@ int unet_op_scratch_bytes(int cin, int cout, int D, int H, int W, size_t* bytes)
     if (cin % 16 == 0 && cout % 16 == 0 && D > 0 && H > 0 && W > 0) {
         ConvGeom g;   // MFMA wgrad slabs: stride-1 geometry has the most tiles
         g.Cin = cin; g.Cout = cout; g.D = g.Do = D; g.H = g.Ho = H; g.W = g.Wo = W; g.ks = 3; g.stride = 1;
-        size_t w = mfma_wgrad_scratch_bytes(g);
+        size_t w = std::max(mfma_wgrad_scratch_bytes(g, 0), mfma_wgrad_scratch_bytes(g, 1));   // unet_op_conv3d_bwd_weight may launch politely (UNET_OP_POLITE): more slab rows
         if (w > b) b = w;
         g.stride = 2; g.Do = (D - 1) / 2 + 1; g.Ho = (H - 1) / 2 + 1; g.Wo = (W - 1) / 2 + 1;
-        w = mfma_wgrad_scratch_bytes(g);
+        w = std::max(mfma_wgrad_scratch_bytes(g, 0), mfma_wgrad_scratch_bytes(g, 1));
         if (w > b) b = w;
         g.Do = 2 * D; g.Ho = 2 * H; g.Wo = 2 * W;   // conv_trans
         w = mfma_convt_wgrad_scratch_bytes(g);

@@ -230,6 +230,17 @@ size_t mfma_conv_dgrad_w_bytes(const ConvGeom& g);
 struct BnBwdStats { const void* u; const float* stat; float* partial; int act, C; };
 int launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s,
                            const BnBwdStats* bn = nullptr);
+// kernels_mfma_s2.hip: sliding-window / LDS-DMA kernels for the contractions that cross a resolution boundary, coarse grid >= 16 wide
+// (the launchers below try them first; 0 / false = shape not served, the halo-tile kernel k_mfma_conv_p runs instead).
+// launch_s2_conv_fwd returns the number of statistics rows; launch_s2_conv_dgrad the number of norm-backward partial rows it left in
+// bn->partial (its destination may be ACCUMULATED into: the old values and the raw tensor travel by LDS-DMA too), -1 without bn
+int launch_s2_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, float* stats_partial,
+                       hipStream_t s);
+int launch_s2_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_s2_dgrad, const DstGrad* dst, int ndst, hipStream_t s,
+                         const BnBwdStats* bn);
+int s2_conv_dgrad_rows_max();
+bool launch_s2_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s);
+bool launch_s2_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
 // ConvTranspose3d 2x2x2 stride 2: forward (1x1 GEMM + depth-to-space scatter) and dgrad (2x2x2 stride-2 conv of dL/dy)
 bool mfma_convt_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_w_bytes(const ConvGeom& g);

@@ -1349,6 +1349,10 @@ int launch_mfma_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const 
     a.out[0] = out; a.outC[0] = g.Cout;
     a.stats = stats_partial;
     a.oD = g.Do; a.oH = g.Ho; a.oW = g.Wo;
+    if (g.stride == 2 && fwd_ck(g) == 16) {      // the sliding-window form reads the 16-channel-chunk pack
+        const int rows = launch_s2_conv_fwd(g, src, nsrc, w_mfma, bias, out, stats_partial, s);
+        if (rows) return rows;
+    }
     return g.stride == 1 ? launch_s1k3(a, fwd_ck(g), s) : launch_s2k3(a, s);
 }
 // dgrad (g = forward geometry).  stride 1: 27-tap conv of dL/dy with the flipped filter.  stride 2: 8-tap conv of
@@ -1377,6 +1381,9 @@ int launch_mfma_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma
         }
         launch_s1k3(a, pick_ck(g.Cout, true), s);
     } else {
+        static const bool no_bn2 = getenv("UNET_NO_DGRAD_BNSTATS") != nullptr;
+        const int rows = launch_s2_conv_dgrad(g, dy, w_mfma_dgrad, dst, ndst, s, no_bn2 ? nullptr : bn);
+        if (rows) return rows > 0 ? rows : 0;
         a.g.Cout = 8 * g.Cin; a.sc_C = g.Cin;
         a.g.Do = (g.D + 1) / 2; a.g.Ho = (g.H + 1) / 2; a.g.Wo = (g.W + 1) / 2;   // coarse positions m with 2m or 2m+1 inside the volume
         launch_k2sc(a, s);
@@ -1400,6 +1407,7 @@ int mfma_convt_pack_jobs(const ConvGeom& g, PackJob* out) {
     return 2;
 }
 void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s) {
+    if (launch_s2_convt_fwd(g, src, nsrc, w_mfma, bias, out, s)) return;
     MfmaConvArgs a = base_args();
     a.g = g; a.g.Cout = 8 * g.Cout; a.g.Do = g.D; a.g.Ho = g.H; a.g.Wo = g.W; a.g.ks = 1; a.g.stride = 1;
     a.nsrc = nsrc; a.src[0] = src[0]; if (nsrc > 1) a.src[1] = src[1];
@@ -1409,6 +1417,7 @@ void launch_mfma_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, cons
     launch_k1sc(a, s);
 }
 void launch_mfma_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s) {
+    if (convt_dgrad_ck(g.Cout, g.W) == 16 && launch_s2_convt_dgrad(g, dy, w_mfma_dgrad, dst, ndst, s)) return;
     MfmaConvArgs a = base_args();
     a.src[0].ptr = dy; a.src[0].C = g.Cout;
     a.w = w_mfma_dgrad;

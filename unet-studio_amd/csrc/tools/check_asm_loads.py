@@ -199,6 +199,110 @@ def scan_dma(body):
     return errors, st
 
 
+def scan_dma_cfg(body):
+    """kernels_mfma_s2.hip (k_s2_scatter / k_s2_gather): the LDS-DMA discipline of scan_dma, checked over the control-flow graph
+    instead of the layout order (the compiler rotates the unrolled step loop and sinks a step's last store below the loop-exit
+    test, so straight-line counting between two waits no longer sees whole steps).
+    From every hand-placed wait all paths are followed to the next hand-placed wait: an exec-mask branch is followed on the side
+    where lanes are active (every wave issues every DMA piece: static_assert in the kernel), a scalar conditional branch on both
+    sides, s_branch to its target.  Required: every path from a steady wait vmcnt(N) to a steady wait carries exactly P LDS-DMA
+    pieces and S buffer_store_dwordx2 and no other vector-memory instruction, N = (P + S) PF - P for an integer PF >= 1, and every
+    path from a vmcnt(0) to the first steady wait (the prologue) carries PF P pieces and PF S stores."""
+    errors = []
+    ins, labels, in_asm = [], {}, False
+    for line in body:
+        t = line.strip()
+        if "#ASMSTART" in t:
+            in_asm = True
+            continue
+        if "#ASMEND" in t:
+            in_asm = False
+            continue
+        if not t or t[0] in ";":
+            continue
+        if t.endswith(":") or re.match(r"^\.?[A-Za-z_][\w.$]*:", t):
+            labels[t.split(":")[0]] = len(ins)
+            continue
+        if t[0] == ".":
+            continue
+        t = t.split(";")[0].strip()
+        if not t:
+            continue
+        ins.append((t.split()[0], t, in_asm))
+    waits = {}
+    wait_at = {}
+    for i, (op, t, a) in enumerate(ins):
+        if a and op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                wait_at[i] = int(m.group(1))
+                waits[wait_at[i]] = waits.get(wait_at[i], 0) + 1
+    steady = sorted(n for n in waits if n)
+    st = {"hand_waits": waits}
+    if len(steady) != 1 or not waits.get(0):
+        errors.append("hand-placed waits %s (expected one steady-state value and vmcnt(0))" % waits)
+        return errors, st
+    N = steady[0]
+    results = {}      # (from kind, to kind) -> set of (dma, store)
+    other = []
+    sys.setrecursionlimit(100000)
+    for start, n0 in wait_at.items():
+        seen = set()
+        stack = [(start + 1, 0, 0)]
+        while stack:
+            i, d, sto = stack.pop()
+            while True:
+                if i >= len(ins):
+                    break
+                if (i, d, sto) in seen:
+                    break
+                seen.add((i, d, sto))
+                op, t, a = ins[i]
+                if i in wait_at:
+                    results.setdefault((n0, wait_at[i]), set()).add((d, sto))
+                    break
+                if op == "s_endpgm":
+                    break
+                if op.startswith("global_load_lds"):
+                    d += 1
+                elif op == "buffer_store_dwordx2":
+                    sto += 1
+                elif op.startswith("scratch_") or op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_"):
+                    if n0 == N:
+                        other.append(t)
+                if op == "s_branch":
+                    i = labels.get(t.split()[1], len(ins))
+                    continue
+                if op in ("s_cbranch_execz", "s_cbranch_execnz"):
+                    i = labels.get(t.split()[1], len(ins)) if op == "s_cbranch_execnz" else i + 1
+                    continue
+                if op.startswith("s_cbranch"):
+                    stack.append((labels.get(t.split()[1], len(ins)), d, sto))
+                i += 1
+    if other:
+        errors.append("vector-memory instruction inside a hand-counted step: %s" % other[0])
+    shapes = results.get((N, N), set())
+    st["steps_checked"] = sum(1 for k in wait_at.values() if k == N)
+    if len(shapes) != 1:
+        errors.append("paths between two steady waits differ in their (DMA pieces, stores): %s" % sorted(shapes))
+        return errors, st
+    pcs, sts = next(iter(shapes))
+    st.update({"dma_pieces_per_step": pcs, "stores_per_step": sts})
+    pf = (N + pcs) / float(pcs + sts) if pcs + sts else 0
+    if pcs == 0 or pf != int(pf) or pf < 1:
+        errors.append("vmcnt(%d) is not (P + S) * PF - P for P = %d pieces, S = %d stores" % (N, pcs, sts))
+        return errors, st
+    pf = int(pf)
+    st["planes_ahead"] = pf
+    pro = results.get((0, N), set())
+    if pro != {(pf * pcs, pf * sts)}:
+        errors.append("prologue paths carry %s (expected %s)" % (sorted(pro), (pf * pcs, pf * sts)))
+    for (a0, b0), sh in results.items():      # a step that leaves the loop may do so only after its full complement (it ends in vmcnt(0))
+        if a0 == N and b0 == 0 and any(x != (pcs, sts) for x in sh):
+            errors.append("a step's path to the final vmcnt(0) carries %s" % sorted(sh))
+    return errors, st
+
+
 def main(which, path, out_json=None):
     text = open(path).read()
     ver = subprocess.run(["hipcc", "--version"], capture_output=True, text=True).stdout.strip().split("\n")
@@ -209,6 +313,10 @@ def main(which, path, out_json=None):
     elif which == "conv_zdma":
         bodies = kernel_bodies(text, "k_mfma_conv_z16") + kernel_bodies(text, "k_mfma_conv_z32")
         mode = "dma"
+    elif which == "s2dma":
+        # kernels_mfma_s2.hip: the same LDS-DMA discipline (P pieces + S stores per wave and step, one hand-counted wait)
+        bodies = kernel_bodies(text, "k_s2_scatter") + kernel_bodies(text, "k_s2_gather")
+        mode = "dma"
     else:
         bodies = kernel_bodies(text, "k_mfma_wgrad_zI")
         mode = "retire"
@@ -217,7 +325,7 @@ def main(which, path, out_json=None):
     for sym, body in bodies:
         meta = metadata(text, sym)
         if mode == "dma":
-            errors, st = scan_dma(body)     # (spills outside the hand-counted steps are harmless here: the steps are checked instruction by instruction)
+            errors, st = scan_dma_cfg(body) if which == "s2dma" else scan_dma(body)     # (spills outside the hand-counted steps are harmless here: the steps are checked instruction by instruction)
             st.update({"asm_loads": st.get("dma_pieces_per_step", 0), "buffer_store_dwordx2": st.get("stores_per_step", 0)})
         else:
             errors, st = scan(body, mode)
@@ -225,7 +333,8 @@ def main(which, path, out_json=None):
                 if meta.get(key) != 0:
                     errors.append("%s = %s (must be 0)" % (key, meta.get(key)))
         if mode == "dma":
-            pass
+            if which == "s2dma" and (meta.get(".vgpr_spill_count") or meta.get(".private_segment_fixed_size")):
+                errors.append("scratch in use: vgpr spills %s, private segment %s" % (meta.get(".vgpr_spill_count"), meta.get(".private_segment_fixed_size")))
         elif which == "conv_z":
             if st["asm_loads"] != 12:
                 errors.append("inline-asm plane loads: %d (expected 12)" % st["asm_loads"])

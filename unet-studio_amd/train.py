@@ -114,12 +114,17 @@ class Trainer:
             count = len(mine)
             mine = []
             overlap = False
+        # workspaces (and the filter packs they hold) are keyed by the sample's spatial size: a micro-step may only skip the repack when a
+        # micro-step of THIS optimizer step (or unet_pack_filters behind the last update) already packed for its size
+        packed_sizes = set()
+        if self._packed_size is not None and self._packed_version == getattr(m, "_params_version", None):
+            packed_sizes.add(self._packed_size)
         for k, b in enumerate(mine):
             x, t = self.source(cur_data_index + b)
             # the parameters only change at the end of the step (train.cpp:765): this rank's micro-steps 2.. reuse the filter packs of its first
-            packed = self._packed_size == tuple(x.shape[2:]) and self._packed_version == getattr(m, "_params_version", None)
-            kw = {"packs_current": True} if (self.packs_reuse and (k > 0 or packed)) else {}
             last_size = tuple(x.shape[2:])
+            kw = {"packs_current": True} if (self.packs_reuse and last_size in packed_sizes) else {}
+            packed_sizes.add(last_size)
             first_direct = k == 0 and self.stats_direct
             if first_direct:
                 kw["losses_out"] = self._stats
@@ -182,6 +187,9 @@ class Trainer:
             lane = self._lanes[k % self.in_flight]
             with tc.stream(lane["stream"]):
                 x, t = self.source(cur_data_index + b)
+                if tuple(x.shape[2:]) != tuple(x0.shape[2:]):
+                    raise ValueError("micro-steps in flight need samples of one size (lane plans were made for %s, got %s)"
+                                     % (tuple(x0.shape[2:]), tuple(x.shape[2:])))
                 # a lane's workspace holds its own filter packs: made by the lane's first micro-step of the step, reused by its later ones
                 l = m.forward_backward_lane(lane, x, t, self._gptrs[k], p.cost_ce, p.cost_dice, p.cost_mse,
                                             packs_current=self.packs_reuse and k >= self.in_flight)

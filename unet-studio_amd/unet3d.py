@@ -208,7 +208,10 @@ class UNet3d:
 
     def save_optimizer(self, file_name):
         """torch::save(*(model->optimizer), model_path + ".opt") -- train.cpp:787: the momentum of the fused update (and the learning
-        rate), so that a run resumed from <model>.nz + <model>.nz.opt continues exactly.  Returns False + error_msg on failure."""
+        rate), so that a run resumed from <model>.nz + <model>.nz.opt continues exactly.  Returns False + error_msg on failure.
+        FORMAT: a torch.save pickle {"momentum_buffer": flat fp32 tensor, "lr": float} -- the Python host's own.  It is NOT the libtorch
+        optimizer archive that the C++ host (unet_host.cpp:save_optimizer) and the reference (train.cpp:787) write with
+        torch::save(*optimizer): a .opt file of one host cannot be loaded by the other (load_optimizer reports "cannot load optimizer")."""
         try:
             if self.optimizer is None:
                 raise E.UNetError("save_optimizer: no optimizer (create_optimizer first)")
