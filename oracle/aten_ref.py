@@ -94,8 +94,79 @@ def create_layer(layers, token, in_c):
     return out_c
 
 
+class _RoundBF16(torch.autograd.Function):
+    """a tensor the MI355X engine STORES as bf16 (include/unet_hip.h, UNET_DTYPE_BF16): the value is rounded where it is stored, and
+    so is its gradient (the gradient buffer of the same tensor is bf16 too)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwdOnly(torch.autograd.Function):
+    """a filter: the engine's matrix-core kernels read a bf16 pack of the fp32 master weights; the weight gradient is fp32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGradOnly(torch.autograd.Function):
+    """a view that is never stored (the engine's fused heads transform the raw tensor as they load it) but whose gradient is"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+_ACTS = (nn.ReLU, nn.LeakyReLU, nn.ELU)
+
+
+def run_bf16_storage(seq, x, last_view_unstored=False):
+    """One nn.Sequential of unet.cpp:103-166 with the roundings of the engine's bf16 configuration (data layout): conv /
+    conv_trans read bf16 filters and store their raw output as bf16; `norm + activation` is evaluated in fp32 on the stored raw tensor
+    and its result (the activated copy every consumer reads) is stored as bf16; gradients are rounded where those tensors' gradient
+    buffers are written.  Arithmetic between the roundings is ATen's fp32.  last_view_unstored: the sequence's last view is read by a
+    fused head only (the decoder's full-resolution output), which keeps no copy."""
+    mods = list(seq)
+    views = [i for i, m in enumerate(mods) if isinstance(m, (nn.InstanceNorm3d, nn.BatchNorm3d) + _ACTS)]
+    last_view = views[-1] if views else -1
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.ConvTranspose3d):
+            x = _RoundBF16.apply(F.conv_transpose3d(x, _RoundFwdOnly.apply(m.weight), m.bias, m.stride))
+        elif isinstance(m, nn.Conv3d):
+            x = _RoundBF16.apply(F.conv3d(x, _RoundFwdOnly.apply(m.weight), m.bias, m.stride, m.padding))
+        elif isinstance(m, (nn.InstanceNorm3d, nn.BatchNorm3d) + _ACTS):
+            x = m(x)
+            if not isinstance(m, _ACTS) and i + 1 < len(mods) and isinstance(mods[i + 1], _ACTS):
+                i += 1
+                x = mods[i](x)
+            x = _RoundGradOnly.apply(x) if (last_view_unstored and i >= last_view) else _RoundBF16.apply(x)
+        else:
+            x = m(x)
+        i += 1
+    return x
+
+
 class UNet3dRef(nn.Module):
-    """unet.cpp:103-166; module registration order fixes parameters() order."""
+    """unet.cpp:103-166; module registration order fixes parameters() order.
+    bf16_storage = True (test infrastructure for the engine's bf16 configuration, not a reference behaviour): forward() rounds to bf16
+    exactly where the engine stores bf16 (run_bf16_storage); the reference itself is fp32 throughout."""
+    bf16_storage = False
 
     def __init__(self, in_count, out_count, architecture):
         super().__init__()
@@ -147,18 +218,26 @@ class UNet3dRef(nn.Module):
         skips = []
         results = [None] * len(self.output)
         n = len(self.encoding)
+        bf = self.bf16_storage
+        if bf:
+            x = x.to(torch.bfloat16).to(x.dtype)      # the engine's input pack
         for level in range(n):
-            x = self.encoding[level](x)
+            x = run_bf16_storage(self.encoding[level], x) if bf else self.encoding[level](x)
             if level < n - 1:
                 skips.append(x)
         for level in range(n - 2, -1, -1):
-            x = torch.cat([skips[level], x], 1)
+            # a tensor with two readers: the reader that comes LATER in the forward writes the gradient buffer first (bf16), the earlier
+            # one adds to it and rounds again -- so the later reader's contribution is rounded on its own
+            x = torch.cat([_RoundGradOnly.apply(skips[level]) if bf else skips[level], x], 1)
             skips[level] = None
-            x = self.decoding[level](x)
+            if bf:   # heads (fp32 weights, fp32 results) read the view; only a head reads the last level's
+                x = run_bf16_storage(self.decoding[level], x, last_view_unstored=len(self.output[level]) > 0 and not len(self.decoding_tail[level]))
+            else:
+                x = self.decoding[level](x)
             if len(self.output[level]):
                 results[level] = self.output[level](x)
             if len(self.decoding_tail[level]):
-                x = self.decoding_tail[level](x)
+                x = run_bf16_storage(self.decoding_tail[level], _RoundGradOnly.apply(x) if len(self.output[level]) else x) if bf else self.decoding_tail[level](x)
         return results
 
     def train(self, on=True):

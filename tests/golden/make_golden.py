@@ -90,12 +90,18 @@ def logit_stride(n, level):
 GRAD_SAMPLE_STRIDE = 997
 
 
-def default_case(n=64):
+def default_case(n=64, variant=""):
     """default architecture (train.cpp:1054-1069), in=1, out=6, weights = module init under manual_seed(0)
     (as the GUI does, mainwindow_training.cpp:253).  Params are 60 MB, so the fixture holds a param checksum,
-    sampled logits, per-tensor grad norms and the leading elements of every grad."""
+    sampled logits, per-tensor grad norms and the leading elements of every grad.
+    variant "elu": every leaky_relu replaced by elu (a smooth activation: fp32 gradients agree to rounding, no kink voxels);
+    variant "bf16": the same ATen kernels with bf16 roundings where the engine's bf16 configuration stores bf16
+    (oracle/aten_ref.py:run_bf16_storage) -- the checker for the benchmarked configuration."""
     arch = A.default_feature(6)
+    if variant == "elu":
+        arch = arch.replace("leaky_relu", "elu")
     m = make_model(arch, 1, 6, perturb=False)
+    m.bf16_storage = variant == "bf16"
     m.train()
     x, t = A.synthetic_sample(1, 6, (n, n, n), 1)
     outs = m(x)
@@ -116,14 +122,24 @@ def default_case(n=64):
     # channel pair) changes these although it leaves grad_l2 and the 16 leading elements alone
     d["grad_sample"] = np.concatenate([p.grad.flatten()[::GRAD_SAMPLE_STRIDE].numpy() for p in m.parameters()])
     d["grad_absmax"] = np.array([float(p.grad.abs().max()) for p in m.parameters()])
-    np.savez_compressed(os.path.join(HERE, "default_arch_%d.npz" % n), **d)
-    print("default", n, "loss", d["loss"], "stats", d["stats"])
+    np.savez_compressed(os.path.join(HERE, "default_arch_%d%s.npz" % (n, "_" + variant if variant else "")), **d)
+    print("default", n, variant, "loss", d["loss"], "stats", d["stats"])
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only == "variants":      # python tests/golden/make_golden.py variants: only the elu / bf16-storage fixtures of the default architecture
+        default_case(64, "elu")
+        default_case(64, "bf16")
+        default_case(128, "bf16")
+        sys.exit(0)
     small_case("cfg1_bnorm_16", ARCH_BN, 1, 6, 16)
     small_case("mix_16", ARCH_MIX, 2, 3, 16)
     small_case("c16_24", ARCH_16, 1, 4, 24, batch_size=2)
     default_case(64)
     default_case(128)   # BASELINE.json's size (config 2: the fp32 parity configuration); ~1 min, ~12 GB
+    if only in ("", "variants"):
+        default_case(64, "elu")
+        default_case(64, "bf16")
+        default_case(128, "bf16")   # the benchmarked configuration (BASELINE.json configs[2])

@@ -241,6 +241,12 @@ int launch_s2_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_s2_dgr
 int s2_conv_dgrad_rows_max();
 bool launch_s2_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out, hipStream_t s);
 bool launch_s2_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, hipStream_t s);
+// kernels_mfma_s2_wgrad.hip: sliding-window weight gradient of Conv3d(k3, s2) (ks = 3: fine = the input, a concat when fine2 != nullptr,
+// coarse = dy) and ConvTranspose3d(k2, s2) (ks = 2: fine = dy, coarse = the input; bias_from_a: the bias partials are sums of the fine
+// tensor).  Kernel only: slab [rows][Cb][Ca][ks^3] (+ [rows][Cb or Ca] bias partials behind it) at `scratch`; returns rows, 0 = not served
+int s2_wgrad_splits(int Ca, int Cb, int cD, int cH, int cW);
+int launch_s2_wgrad(int ks, const void* fine, const void* fine2, int C0, int Ca, int fD, int fH, int fW, const void* coarse, int Cb, int cD, int cH,
+                    int cW, bool want_bias, int bias_from_a, void* scratch, hipStream_t s, int polite);
 // ConvTranspose3d 2x2x2 stride 2: forward (1x1 GEMM + depth-to-space scatter) and dgrad (2x2x2 stride-2 conv of dL/dy)
 bool mfma_convt_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_w_bytes(const ConvGeom& g);

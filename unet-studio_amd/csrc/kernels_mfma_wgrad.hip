@@ -794,12 +794,17 @@ static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
     c.nsplit = tiles < want ? tiles : want;
     return c;
 }
+// rows of the sliding-window stride-2 / conv_trans kernel (kernels_mfma_s2_wgrad.hip), 0 = not served
+static int s2w_rows_conv(const ConvGeom& g) { return (g.ks == 3 && g.stride == 2) ? s2_wgrad_splits(g.Cin, g.Cout, g.Do, g.Ho, g.Wo) : 0; }
+static int s2w_rows_convt(const ConvGeom& g) { return s2_wgrad_splits(g.Cout, g.Cin, g.D, g.H, g.W); }
 size_t mfma_wgrad_scratch_bytes(const ConvGeom& g, int polite) {
     if (size_t z = mfma_wgrad_z_scratch_bytes(g, polite)) return z;
+    if (int r = s2w_rows_conv(g)) return ((size_t)r * 27 * g.Cin * g.Cout + (size_t)r * g.Cout) * 4 + 256;
     WgradCfg c = wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo);
     return ((size_t)c.nsplit * 27 * g.Cin * g.Cout + (size_t)c.nsplit * g.Cout) * 4 + 256;
 }
 size_t mfma_convt_wgrad_scratch_bytes(const ConvGeom& g) {
+    if (int r = s2w_rows_convt(g)) return ((size_t)r * 8 * g.Cin * g.Cout + (size_t)r * g.Cout) * 4 + 256;
     WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
     return ((size_t)c.nsplit * 8 * g.Cin * g.Cout + (size_t)c.nsplit * g.Cout) * 4 + 256;
 }
@@ -840,20 +845,32 @@ static void launch_wgrad_p(const MfmaWgradArgs& a, const WgradCfg& c, hipStream_
 // rows of the slab a launch leaves at `scratch` ([rows][27*Cin*Cout], then [rows][Cout] bias partials): plan-time constant
 int mfma_conv_wgrad_splits(const ConvGeom& g, int polite) {
     if (int z = mfma_wgrad_z_splits(g, polite)) return z;
+    if (int r = s2w_rows_conv(g)) return r;
     return wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo).nsplit;
 }
-int mfma_convt_wgrad_splits(const ConvGeom& g) { return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).nsplit; }
+int mfma_convt_wgrad_splits(const ConvGeom& g) {
+    if (int r = s2w_rows_convt(g)) return r;
+    return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).nsplit;
+}
 // the launch adds into the gradient itself (no slab, nothing for a reduce pass to do)
 bool mfma_conv_wgrad_direct(const ConvGeom& g) {
-    if (mfma_wgrad_z_splits(g)) return false;
+    if (mfma_wgrad_z_splits(g) || s2w_rows_conv(g)) return false;
     return wgrad_cfg(g.stride == 1 ? 0 : 1, g.Cin, g.Cout, g.Do, g.Ho, g.Wo).direct != 0;
 }
-bool mfma_convt_wgrad_direct(const ConvGeom& g) { return wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).direct != 0; }
+bool mfma_convt_wgrad_direct(const ConvGeom& g) { return !s2w_rows_convt(g) && wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W).direct != 0; }
 // defer_reduce: leave the slab for the caller's batched reduce (launch_wgrad_reduce_batched) instead of summing it here
 void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* dw, float* db, void* scratch,
                             hipStream_t s, bool defer_reduce, int polite) {
     if (mfma_wgrad_z_supported(1, g, src, nsrc)) {   // sliding-window kernel (kernels_mfma_wgrad_z.hip): stride 1, W >= 24
         const int ns = launch_mfma_wgrad_z(g, src, nsrc, dy, db != nullptr, scratch, s, polite);
+        const float* slab = (const float*)scratch;
+        if (!defer_reduce)
+            wgrad_reduce(slab, db ? slab + (size_t)ns * 27 * g.Cin * g.Cout : nullptr, ns, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
+        return;
+    }
+    if (s2w_rows_conv(g)) {     // sliding-window stride-2 kernel (kernels_mfma_s2_wgrad.hip): coarse grid >= 24 wide
+        const int ns = launch_s2_wgrad(3, src[0].ptr, nsrc > 1 ? src[1].ptr : nullptr, src[0].C, g.Cin, g.D, g.H, g.W, dy, g.Cout, g.Do, g.Ho, g.Wo,
+                                       db != nullptr, 0, scratch, s, polite);
         const float* slab = (const float*)scratch;
         if (!defer_reduce)
             wgrad_reduce(slab, db ? slab + (size_t)ns * 27 * g.Cin * g.Cout : nullptr, ns, (int64_t)27 * g.Cin * g.Cout, g.Cout, dw, db, s);
@@ -892,6 +909,13 @@ void launch_mfma_conv_wgrad(const ConvGeom& g, const SrcDesc* src, int nsrc, con
 // halo side A = dy (fine, Cout channels), tile side B = transformed input (coarse, Cin channels): D_t[co][ci].
 void launch_mfma_convt_wgrad(const ConvGeom& g, const SrcDesc* src, const void* dy, float* dw, void* scratch, hipStream_t s, bool defer_reduce,
                              float* db, int polite) {
+    if (s2w_rows_convt(g)) {    // fine = dy (Ca = Cout), coarse = the input (Cb = Cin): slab [Cin][Cout][8] = the layout of dw; bias = sums of dy
+        const int ns = launch_s2_wgrad(2, dy, nullptr, g.Cout, g.Cout, g.Do, g.Ho, g.Wo, src[0].ptr, g.Cin, g.D, g.H, g.W, db != nullptr, 1, scratch, s, polite);
+        const float* slab = (const float*)scratch;
+        if (!defer_reduce)
+            wgrad_reduce(slab, db ? slab + (size_t)ns * 8 * g.Cin * g.Cout : nullptr, ns, (int64_t)8 * g.Cin * g.Cout, g.Cout, dw, db, s);
+        return;
+    }
     WgradCfg c = wgrad_cfg(2, g.Cout, g.Cin, g.D, g.H, g.W);
     c.polite = polite;
     MfmaWgradArgs a;
