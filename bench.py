@@ -132,10 +132,12 @@ def cpu_baseline(size, budget_steps=3):   # ~3 s per 128^3 step on 16 cores: 1 w
     """ATen-CPU train micro-step (forward + losses + backward + step epilogue), fp32, all host cores."""
     from oracle import aten_ref as A
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))   # a 1-GPU box's CPU share is 16 cores
+        avail = os.cpu_count() or 1
+    # threads = the process's CPU share: a one-GPU box of this pool grants 16 cores to a job (worker pools must be sized to it) whatever
+    # the host's core count; torch threads beyond the share only oversubscribe it
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = A.UNet3dRef(1, 6, A.default_feature(6))
@@ -155,7 +157,8 @@ def cpu_baseline(size, budget_steps=3):   # ~3 s per 128^3 step on 16 cores: 1 w
     dt = (time.time() - t0) / budget_steps
     return {"value": size ** 3 / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
             "sample": "%d train steps (1 warm-up) of the default arch at %d^3, fp32, ATen CPU kernels in unet.cpp order "
-                      "(oracle/aten_ref.py), torch %s" % (budget_steps, size, torch.__version__),
+                      "(oracle/aten_ref.py), torch %s; %d threads = the job's CPU share on a one-GPU box (16 cores; %d visible to the process)"
+                      % (budget_steps, size, torch.__version__, cores, avail),
             "ms_per_step": dt * 1e3}
 
 
@@ -265,6 +268,23 @@ def step_roofline(plan, prof_per, ms_per_step, peak, esize, n_params):
     return out
 
 
+def cpp_host_step(n, steps, warmup, dtype):
+    """the same optimizer step driven by the C++ drop-in host (include/unet.hpp + unet_host.cpp: loss_and_backward + sgd_step --
+    what train.cpp's thread C would call), timed by unet-studio_amd/bench_host in a child process of its own"""
+    import subprocess
+    exe = os.path.join(ROOT, "unet-studio_amd", "bench_host")
+    if not os.path.exists(exe):
+        return {"error": "unet-studio_amd/bench_host is not built (__graft_entry__.build())"}
+    try:
+        r = subprocess.run([exe, str(n), str(steps), str(warmup), dtype], capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": "bench_host rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        return json.loads(line[-1])
+    except Exception as e:   # noqa: BLE001  (a reported field, never fatal for the bench line)
+        return {"error": str(e)}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -319,6 +339,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event profile (roofline / conv_mfma_frac)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the single-kernel micro-benchmarks (roofline_kernels)")
+    ap.add_argument("--no-cpp-host", action="store_true", help="skip timing the same step through the C++ host (unet-studio_amd/bench_host)")
     ap.add_argument("--batch", type=int, default=None, help="(default: 8 on one GPU, 0 = off on several) the reference's step shape (train.cpp:604-606: batch_size micro-steps per update, "
                     "train.hpp:12 default 32; SURVEY 8(d) config 3 asks for 8): B micro-steps per GPU per optimizer step, timed AFTER the "
                     "headline and reported as `batch<B>` inside the same line; 0 = skip")
@@ -344,8 +365,6 @@ def main():
         raise SystemExit("bench.py --gpus %d: %d devices needed, %d visible" % (a.gpus, a.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
-    if os.environ.get("UNET_BENCH_STREAM"):     # experiment: the whole run on a stream of torch's pool instead of the null stream
-        torch.cuda.set_stream(torch.cuda.Stream(dev))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -386,6 +405,18 @@ def main():
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt)
+    # who took part: lets a reader of the line confirm the rank count and that the collectives ran over RCCL (gathered FROM the ranks)
+    me = {"rank": rank, "device": torch.cuda.get_device_name(dev), "local_device": str(dev), "pid_host": os.uname().nodename}
+    comm_info = {"backend": None, "world_size": 1, "rccl_version": None, "ranks": [me]}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        comm_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver, "ranks": gathered,
+                     "gradient_allreduce": "flat fp32 gradient buffer, %d elements, bucketed under the backward (train.py: Trainer.step)" % model.flat_grads.numel()}
     loss = float(trainer._stats[0]) / max(1, len(range(rank, world, world)))
 
     # the reference's own step shape: batch_size micro-steps per update (train.cpp:604-606,759-761), here B per GPU per step.  Clip,
@@ -430,9 +461,12 @@ def main():
             "step_mfma_frac": (step_flops * world * a.steps / dt) / (peak * world),
             "last_loss": loss,
         }
+        out["comm"] = comm_info
         kernels = []
         if a.batch > 0:
             out["batch%d" % a.batch] = batch_line
+        if world == 1 and not a.no_cpp_host and not a.augment and cin == 1:
+            out["cpp_host"] = cpp_host_step(n, a.steps, a.warmup, a.dtype)
         if world == 1 and not a.no_profile:
             # (ranks > 1 would need the other ranks to join the profiled steps' collectives: the profile is a single-GPU measurement)
             prof = profile_steps(U, trainer, plan, peak)

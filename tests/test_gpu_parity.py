@@ -406,7 +406,7 @@ def test_default_arch_bf16_against_the_bf16_storage_oracle(golden_dir, size):
     inside a layer and the roundings it flips, so the bounds are several times tighter than against the fp32 reference
     (test_default_arch_128_bf16_against_golden: 4e-2 / 8e-2 logits, 0.4 of a tensor's max on gradient samples): logits 1e-2 at the two
     finest levels and 2e-2 below, loss 2e-3, filter-gradient norms 3e-2 (measured 1.4e-2), sampled elements of every gradient tensor of >= 1024
-    elements 0.12 of the tensor's max (measured 9e-2), and the small tensors (norm scales / shifts, biases: < 1024 elements) by their norm, 0.15."""
+    elements 0.2 of the tensor's max (measured 7e-2 .. 1.3e-1), and the small tensors (norm scales / shifts, biases: < 1024 elements) by their norm, 0.15."""
     d = np.load(os.path.join(golden_dir, "default_arch_%d_bf16.npz" % size))
     n = int(d["n"])
     torch.manual_seed(0)
@@ -449,10 +449,11 @@ def test_default_arch_bf16_against_the_bf16_storage_oracle(golden_dir, size):
     # by the time the gradient has crossed the network, and the sums cancel to about a tenth of their terms' random-walk size (measured:
     # 8.8e-2 on encode0.4.weight at 128^3, 7.7e-2 on encode1.4.bias at 64^3).  A wrong statistic (mean / rstd / a dropped term) is off by O(1).
     assert rel_l2[small].max() < 0.15, "gradient norm of parameter %d: %.3e" % (int(order_s[0]), rel_l2[small].max())
-    # sampled elements of the filters' gradients: measured 9.1e-2 (128^3) / 6.6e-2 (64^3) of the tensor's max, both on encode0.3.weight
-    # (16 -> 16 at full resolution: every element a sum over the whole volume of products of two noisy bf16 tensors); the same tensor's
-    # NORM agrees to 1.2e-2.  (Against the fp32 reference the bound is 0.4.)  A permuted tap or transposed channel pair is off by O(1).
-    worst = _check_grad_samples(m, d, big, 0.12, min_numel=1024)
+    # sampled elements of the filters' gradients: measured 7e-2 .. 1.3e-1 of the tensor's max, depending on which kernel variant sums in
+    # which order (9.1e-2 at 128^3 and 6.6e-2 at 64^3 on encode0.3.weight -- every element a sum over the whole volume of products of two
+    # noisy bf16 tensors --, 1.27e-1 at 64^3 on a 16^3-level filter after the weight gradients moved to LDS-DMA staging); the same tensors'
+    # NORMS agree to 1.4e-2.  (Against the fp32 reference the bound is 0.4.)  A permuted tap or transposed channel pair is off by O(1).
+    worst = _check_grad_samples(m, d, big, 0.2, min_numel=1024)
     print("bf16 vs bf16-storage oracle at %d^3: logits %.3e, gradient norms %.3e, gradient samples %.3e of the tensor's max"
           % (size, worst_logit, rel_l2[big].max(), worst))
 
@@ -885,12 +886,12 @@ def test_norm_backward_statistics_in_the_small_volume_dgrad_epilogue_match_the_s
 def test_stride2_dgrad_statistics_epilogue_and_kernels_match_the_separate_pass_and_the_halo_tile_kernels(tmp_path):
     """kernels_mfma_s2.hip in the network: the stride-2 conv reads the skip tensor, whose gradient has two writers -- its dgrad
     (k_s2_scatter) ACCUMULATES into it (old values by LDS-DMA) and, as the last writer, leaves the norm backward's statistics
-    (UNET_NO_DGRAD_BNSTATS=1: separate k_norm_bwd_stats8 pass; UNET_NO_S2_KERNELS=1: the halo-tile kernels for every stride-2 /
+    (UNET_NO_DGRAD_BNSTATS=1: separate k_norm_bwd_stats8 pass; UNET_NO_SLIDING_WINDOW=1: the halo-tile kernels for every conv /
     conv_trans op).  At 64^3 the small U-Net's coarse level is 32^3: all four new kernels run.  Each variant in a fresh process (the
     switches are read once).  The statistics agree to summation order, so encode0.4's norm parameters do; the rest sees bf16 rounding flips."""
     g1, names = _grads_in_fresh_process(tmp_path, "s2_fused", 64, {})
     g0, _ = _grads_in_fresh_process(tmp_path, "s2_separate", 64, {"UNET_NO_DGRAD_BNSTATS": "1"})
-    g2, _ = _grads_in_fresh_process(tmp_path, "s2_old", 64, {"UNET_NO_S2_KERNELS": "1"})
+    g2, _ = _grads_in_fresh_process(tmp_path, "s2_old", 64, {"UNET_NO_SLIDING_WINDOW": "1"})
     a1, a0, a2 = _by_name(g1, names), _by_name(g0, names), _by_name(g2, names)
     assert np.abs(g1 - g0).max() > 0 and np.abs(g1 - g2).max() > 0, "the switches did not reach the engine"
     for nm in ("encode0.4.weight", "encode0.4.bias"):      # fp32 sums over 64^3 voxels with cancellation, grouped differently: measured 7e-5
@@ -899,6 +900,31 @@ def test_stride2_dgrad_statistics_epilogue_and_kernels_match_the_separate_pass_a
     # against the halo-tile kernels: same arithmetic in another summation order (fp32 accumulators, then bf16 roundings downstream)
     for nm in a2:
         assert np.abs(a1[nm] - a2[nm]).max() <= 2e-2 * max(np.abs(a2[nm]).max(), 1e-3 * np.abs(g2).max()), nm
+
+
+def test_halo_tile_kernels_still_match_the_oracle():
+    """UNET_NO_SLIDING_WINDOW=1 (mfma_util.h) is the documented fallback of every kernel that counts its vector-memory operations by
+    hand (k_mfma_conv_z / _z16 / _z32, k_mfma_wgrad_z / _zd, k_s2_*): all shapes then run on the halo-tile kernels k_mfma_conv_p /
+    k_mfma_conv_small / k_mfma_wgrad.  Those must stay correct for it to BE a fallback: the bf16 op cases run again in a child with
+    the switch set (read once per process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, UNET_NO_SLIDING_WINDOW="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                          "-p", "no:cacheprovider", "-k", "(test_conv3d_ops or test_convt_ops) and bf16"], capture_output=True, text=True, timeout=900,
+                         env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
+def test_one_stream_equals_two_streams_bit_for_bit(tmp_path):
+    """UNET_NO_SIDE_STREAM=1 (engine.cpp; the diagnostic that profiles/stretch.py and the per-op profiler build on) puts the filter
+    packs, the coarse levels' loss and every weight gradient on the caller's stream.  The two streams never write the same buffer and
+    every reduction has a fixed order, so the gradients must be IDENTICAL -- fresh processes, the switch is read once."""
+    g1, _ = _grads_in_fresh_process(tmp_path, "two_streams", 32, {}, arch="default")
+    g0, _ = _grads_in_fresh_process(tmp_path, "one_stream", 32, {"UNET_NO_SIDE_STREAM": "1"}, arch="default")
+    assert np.array_equal(g1, g0)
 
 
 def test_weight_gradients_in_the_polite_launch_configuration():

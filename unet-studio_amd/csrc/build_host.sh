@@ -17,4 +17,7 @@ fi
 if [ ! -f ../test_nz_io ] || [ ../../tests/cpp/test_nz_io.cpp -nt ../test_nz_io ] || [ ../libunet_host.so -nt ../test_nz_io ]; then
     g++ -std=c++17 -O1 $DEF $INC ../../tests/cpp/test_nz_io.cpp -o ../test_nz_io -L.. -lunet_host $LIBS
 fi
+if [ ! -f ../bench_host ] || [ bench_host.cpp -nt ../bench_host ] || [ ../libunet_host.so -nt ../bench_host ]; then
+    g++ -std=c++17 -O1 $DEF $INC bench_host.cpp -o ../bench_host -L.. -lunet_host $LIBS
+fi
 echo "built $(cd .. && pwd)/libunet_host.so and test_unet_hpp"

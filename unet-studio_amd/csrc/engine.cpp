@@ -111,7 +111,7 @@ struct unet_plan {
     // backward side stream: the parameter-gradient kernels (wgrad, its reduce, bias grad) of a layer run beside the
     // dgrad -> norm-backward chain of the next one (they only share read-only inputs); forked / joined with events
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr, ev_deep = nullptr, ev_packd = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr, ev_packd = nullptr;
     // the training forward packs the filters in three launches on the side stream.  The job table holds every op's FORWARD pack first
     // (op order), then every DGRAD pack: [0, pack_split_blocks) = forward packs of the ops before pack_split_op (the encoder's top
     // levels: a few hundred KB), [pack_split_blocks, pack_fwd_blocks) = the other forward packs (the deep levels and the decoder; only
@@ -129,7 +129,6 @@ struct unet_plan {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_pack) (void)hipEventDestroy(ev_pack);
-        if (ev_deep) (void)hipEventDestroy(ev_deep);
         if (ev_packd) (void)hipEventDestroy(ev_packd);
         if (side) (void)hipStreamDestroy(side);
     }
@@ -142,55 +141,37 @@ struct unet_plan {
         cg.ks = op.ks; cg.stride = op.stride;
         return cg;
     }
-    // Which weight-gradient launches are "polite" (ConvGeom::polite; one 4-wave block per CU).  The backward walks the ops from the last
-    // to the first: the decoder's top levels (their gradients are HELD, see backward()), then the small levels, then the encoder's top
-    // levels.  Everything that runs on the side stream while the caller's stream still has latency-bound small kernels ahead is polite;
-    // the encoder's top levels are the tail of the step -- nothing is left to run beside them, they get the whole chip.
-    // UNET_SIDE_POLITE=0: none.  Measured (profiles/r10e_ab_polite_policy.txt): polite for the tail as well is as fast or faster
-    // (2.915-2.93 vs 2.94 ms), so that is the default; UNET_POLITE_TAIL_FULL=1 gives the tail the whole chip.
+    // Which weight-gradient launches are "polite" (one 4-wave block per CU: mfma_util.h polite_lds): every one that runs on the side
+    // stream.  The backward walks the ops from the last to the first -- the decoder's top levels (their gradients are HELD, see
+    // backward()), then the small levels, then the encoder's top levels; polite launches for the tail of the step as well measured as
+    // fast or faster than giving those the whole chip (profiles/r10e_ab_polite_policy.txt: 2.915-2.93 vs 2.94 ms).
     std::vector<int> side_polite;
-    // Weight gradients that run on the CALLER's stream (full occupancy, slab summed there too): the stride-2 conv at the top of the encoder.
-    // Its kernel becomes ready together with its own dgrad at the tail of the backward, where nothing latency-bound is left to hide it
-    // behind, and the two side by side took longer than one after the other (154 us against 55 + 49: both stream the same 64-MB tensors
-    // through the same L2s; profiles/r10h_ab_tail_on_main.txt: step 2.92 -> 2.88 ms).  UNET_TAIL_MAIN=<bit mask> overrides: bit k = the
-    // k-th conv after the first one, in forward order, before the small levels (0 = none).
+    // Weight gradients that run on the CALLER's stream (full occupancy, slab summed there too): the stride-2 convs above 32^3 (the top of
+    // the encoder).  Such a kernel becomes ready together with its own dgrad at the tail of the backward, where nothing latency-bound is
+    // left to hide it behind, and the two side by side took longer than one after the other (154 us against 55 + 49: both stream the same
+    // 64-MB tensors through the same L2s; profiles/r10h_ab_tail_on_main.txt: step 2.92 -> 2.88 ms; the stride-1 layer after it loses 0.03 ms).
     std::vector<char> wgrad_on_main;
     void choose_polite() {
         side_polite.assign(g.ops.size(), 0);
         wgrad_on_main.assign(g.ops.size(), 0);
-        {
-            static const int mask = getenv("UNET_TAIL_MAIN") ? atoi(getenv("UNET_TAIL_MAIN")) : -1;
-            int k = -1;
-            for (size_t i = 0; i < g.ops.size(); ++i) {
-                const Op& op = g.ops[i];
-                if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
-                if (g.tensors[op.dst].voxels() <= (int64_t)32 * 32 * 32) break;
-                if (k >= 0 && (mask >= 0 ? ((mask >> k) & 1) != 0 : (op.kind == OP_CONV && op.stride == 2))) wgrad_on_main[i] = 1;
-                ++k;
-            }
-        }
-        const char* e = getenv("UNET_SIDE_POLITE");
-        if (e && e[0] == '0' && e[1] == 0) return;
-        static const bool all = getenv("UNET_POLITE_TAIL_FULL") == nullptr;
-        const int64_t deep = (int64_t)32 * 32 * 32;
-        int last_deep = -1;
+        bool first = true, any_deep = false;
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
             if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
-            if (g.tensors[op.dst].voxels() <= deep) last_deep = (int)i;
+            if (g.tensors[op.dst].voxels() <= (int64_t)32 * 32 * 32) { any_deep = true; break; }
+            if (!first && op.kind == OP_CONV && op.stride == 2) wgrad_on_main[i] = 1;
+            first = false;
         }
-        if (last_deep < 0) return;
+        if (!any_deep) return;      // a network without small levels has nothing latency-bound to be polite to
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
-            if (op.kind != OP_CONV && op.kind != OP_CONVT) continue;
-            side_polite[i] = (all || g.tensors[op.dst].voxels() <= deep || (int)i > last_deep) && !wgrad_on_main[i] ? 1 : 0;
+            if (op.kind == OP_CONV || op.kind == OP_CONVT) side_polite[i] = wgrad_on_main[i] ? 0 : 1;
         }
     }
 
     // tensor t is read by fused heads only (bf16): see layout()
     bool head_only(size_t t) const {
-        static const bool off = getenv("UNET_HEAD_VIEW") && getenv("UNET_HEAD_VIEW")[0] == '0';
-        if (off || dtype != UNET_DTYPE_BF16 || g.tensors[t].norm < 0 || g.tensors[t].C % 16) return false;
+        if (dtype != UNET_DTYPE_BF16 || g.tensors[t].norm < 0 || g.tensors[t].C % 16) return false;
         int readers = 0;
         for (const Op& op : g.ops) {
             if (op.kind == OP_NORM) continue;
@@ -224,7 +205,6 @@ struct unet_plan {
             // 2.5x halo re-reads), the separate 2-pass copy ~0.03 ms.  288 GB of HBM makes the extra tensor free.
             // ... except for a tensor whose only readers are fused heads (the decoder's last tensor at full resolution): the head kernels are
             // bandwidth-bound element-wise passes that transform as they load, so the copy (read + write of 64 MB at 128^3) is never made.
-            // (UNET_HEAD_VIEW=0 keeps the copy.)
             if (impl == UNET_IMPL_AUTO && (g.tensors[i].norm >= 0 || g.tensors[i].act != ACT_NONE) && !head_only(i))
                 a_off[i] = take((size_t)g.tensors[i].numel() * elsize);
         }
@@ -473,7 +453,7 @@ struct Exec {
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
         std::vector<char> fused_dbl(g.norms.size(), 0);     // ... as fp64 rows (the fp32 engine)
         // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
-        bool packed = false, pack_pending = false, pack2_pending = false, dgrad_deferred = false;
+        bool packed = false, pack_pending = false, pack2_pending = false;
         if (p.jobs_dev && packs_current) packed = true;
         else if (p.jobs_dev) {
             bool flat = true;
@@ -487,24 +467,19 @@ struct Exec {
                 if (mode == 1 && p.side && !no_side && !g_prof) {
                     HIP_OK(hipEventRecord(p.ev_fork, s));
                     HIP_OK(hipStreamWaitEvent(p.side, p.ev_fork, 0));
-                    static const bool one_pack = getenv("UNET_PACK_ONE_LAUNCH") != nullptr;
-                    if (p.pack_split_op > 0 && p.pack_split_blocks > 0 && !one_pack) {
+                    if (p.pack_split_op > 0 && p.pack_split_blocks > 0) {
+                        // three launches: the top levels' forward packs (a few hundred KB: the first MFMA conv waits for these only), the
+                        // other forward packs, the dgrad packs (nothing reads them before the backward).  Measured and not kept: a bounded
+                        // grid for the later launches (no gain), the dgrad packs launched when the caller's stream reaches the 16^3 level
+                        // (2.925-2.935 ms against 2.915: their 5800 short blocks delay the small levels' latency-bound kernels by more
+                        // than they cost the bandwidth-bound ones), one launch for everything (a 20-us bubble in front of the first MFMA conv).
                         launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_split_blocks, p.side);
                         HIP_OK(hipEventRecord(p.ev_join, p.side));
-                        // UNET_PACK_GRID: bound on the number of blocks of the later launches (0 = a block per unit; measured: no gain)
-                        static const int pack_grid = getenv("UNET_PACK_GRID") ? atoi(getenv("UNET_PACK_GRID")) : 0;
-                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_fwd_blocks - p.pack_split_blocks, p.side,
-                                                 p.pack_split_blocks, pack_grid);
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_fwd_blocks - p.pack_split_blocks, p.side, p.pack_split_blocks);
                         HIP_OK(hipEventRecord(p.ev_pack, p.side));
                         pack2_pending = true;
-                        // the dgrad packs: right away.  (UNET_PACK_DGRAD_LATE=1: when the caller's stream reaches pack_split_op, beside the small
-                        // levels instead of beside the first full-resolution convs -- measured 2.925-2.935 ms against 2.915: the 5800 short
-                        // blocks delay the small levels' latency-bound kernels by more than they cost the bandwidth-bound ones.)
-                        static const bool early = getenv("UNET_PACK_DGRAD_LATE") == nullptr;
-                        if (early) {
-                            launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks, pack_grid);
-                            HIP_OK(hipEventRecord(p.ev_packd, p.side));
-                        } else dgrad_deferred = true;
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks);
+                        HIP_OK(hipEventRecord(p.ev_packd, p.side));
                     } else {
                         launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks, p.side);
                         HIP_OK(hipEventRecord(p.ev_join, p.side));
@@ -522,18 +497,8 @@ struct Exec {
             if (pack_pending) { HIP_OK(hipStreamWaitEvent(s, p.ev_join, 0)); pack_pending = false; }
             if (pack2_pending && op_index >= p.pack_split_op) { HIP_OK(hipStreamWaitEvent(s, p.ev_pack, 0)); pack2_pending = false; }
         };
-        auto launch_dgrad_packs = [&]() {      // behind everything the caller's stream has been given so far
-            if (!dgrad_deferred) return;
-            dgrad_deferred = false;
-            static const int pack_grid = getenv("UNET_PACK_GRID_LATE") ? atoi(getenv("UNET_PACK_GRID_LATE")) : 0;
-            HIP_OK(hipEventRecord(p.ev_deep, s));
-            HIP_OK(hipStreamWaitEvent(p.side, p.ev_deep, 0));
-            launch_mfma_pack_batched(params[0], ws, p.jobs_dev, (int)p.pack_jobs.size(), p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks, pack_grid);
-            HIP_OK(hipEventRecord(p.ev_packd, p.side));
-        };
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
-            if ((int)i == p.pack_split_op) launch_dgrad_packs();
             ProfScope ps((int)i, (op.kind == OP_CONV || op.kind == OP_CONVT) ? UNET_PROF_CONV_FWD : op.kind == OP_NORM ? UNET_PROF_NORM_FWD : UNET_PROF_OTHER, s);
             switch (op.kind) {
                 case OP_PACK_INPUT:
@@ -586,8 +551,7 @@ struct Exec {
                         // fp32 engine: the same IEEE fp32 products and sums as the VALU kernel below, on the fp32 matrix cores
                         if (!packs_current) launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         const Tensor& T = g.tensors[op.dst];
-                        static const bool no_f32_stats = getenv("UNET_NO_F32_STATS_EPILOGUE") != nullptr;
-                        const bool want_stats = !no_f32_stats && T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
+                        const bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
                         const int rows = launch_conv_f32_mfma(cg, sd, op.nsrc, wf, params[op.bias], (float*)tptr(op.dst), s,
                                                               want_stats ? (double*)partial() : nullptr);
                         if (want_stats) { fused_blocks[T.norm] = rows; fused_dbl[T.norm] = 1; }
@@ -663,7 +627,6 @@ struct Exec {
             if (on_head && op.out_level >= 0 && outs && outs[op.out_level] && (op.kind == OP_CONV || op.kind == OP_CONVT || op.kind == OP_EXPORT))
                 (*on_head)(op.out_level);
         }
-        launch_dgrad_packs();
         need_packs();   // nothing consumed the packs (no MFMA op): still order the caller's stream after the side stream
     }
 
@@ -787,23 +750,20 @@ struct Exec {
                 launch_convt_wgrad_direct(p.dtype, cg, sd, op.nsrc, gptr(t), gparams[op.weight], gparams[op.bias], ws + p.wgrad_off, sb);
             }
             }
-            static const int wz_every = getenv("UNET_WZ_FLUSH") ? atoi(getenv("UNET_WZ_FLUSH")) : 3;   // experiment knob
-            if (wz_pending >= wz_every) flush_wz(sb);
+            if (wz_pending >= 3) flush_wz(sb);      // (every layer and one flush at the end both measured slower: profiles/r06 A/Bs)
         };
         // The backward starts at full resolution, where the caller's stream is bandwidth-bound, and then spends a long stretch in the
         // small levels, where it is launch-latency bound and the memory system idles.  The big weight gradients of the decoder's top
         // levels (everything they read stays in the workspace: each tensor has a gradient buffer of its own) are therefore HELD until
         // the caller's stream reaches the small levels and run beside those, instead of competing with the top levels' dgrad / norm
-        // kernels for bandwidth.  (UNET_WGRAD_HOLD=0: every gradient as soon as its inputs are final.)
-        static const bool hold_on = !(getenv("UNET_WGRAD_HOLD") && getenv("UNET_WGRAD_HOLD")[0] == '0');
-        const int64_t hold_from = hold_on ? (int64_t)64 * 64 * 64 : INT64_MAX, hold_below = (int64_t)32 * 32 * 32;
+        // kernels for bandwidth.
+        const int64_t hold_from = (int64_t)64 * 64 * 64, hold_below = (int64_t)32 * 32 * 32;
         std::vector<int> held;
         bool deep_seen = false;
         // An event record on the caller's stream is not free: the kernel behind it starts ~6 us late (time line of a step,
         // profiles/r07_timeline.txt: every dgrad that follows a fork).  The weight gradient of a layer can start any time after its
-        // dL/d(raw output) is final, so forks are shared: layers wait in `pending` and ONE fork serves `fork_every` of them
-        // (UNET_FORK_EVERY, 1 = a fork per layer as in round 2).
-        static const int fork_every = getenv("UNET_FORK_EVERY") ? std::max(1, atoi(getenv("UNET_FORK_EVERY"))) : 3;
+        // dL/d(raw output) is final, so forks are shared: layers wait in `pending` and ONE fork serves `fork_every` of them.
+        constexpr int fork_every = 3;
         std::vector<int> pending;
         auto issue_pending = [&]() {
             if (pending.empty()) return;
@@ -832,8 +792,7 @@ struct Exec {
                     if (!dry) {
                         // the slab sum that finishes the head's dW / db feeds nothing on the caller's chain: on the side stream (a slab region
                         // per head, so the next level's head does not overwrite rows that have not been summed yet)
-                        static const bool head_side = getenv("UNET_HEAD_REDUCE_MAIN") == nullptr;
-                        const bool defer = head_side && sb != s && p.head_op_off[i] != SIZE_MAX;
+                        const bool defer = sb != s && p.head_op_off[i] != SIZE_MAX;
                         char* hs = ws + (defer ? p.head_op_off[i] : p.head_off);
                         launch_head_bwd(p.dtype, geom(op), src(op.src[0]), grad_outs[op.out_level], nullptr, params[op.weight], dgh,
                                         gparams[op.weight], gparams[op.bias], hs, s, defer);
@@ -1036,20 +995,14 @@ int unet_plan_create(const char* arch, int in_c, int out_c, int D, int H, int W,
             DeviceGuard dg(device);
             int pr_least = 0, pr_greatest = 0;   // the side stream yields to the caller's (critical-path) stream
             (void)hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
-            // UNET_SIDE_CUS=<n>: the side stream may use n CUs of every XCD (a CU mask; bit i of the mask = CU i / 8 of XCD i % 8 on this
-            // part -- profiles/tools/cu_mask_probe.hip; a mask that leaves an XCD without CUs is ignored by the driver), so that the
-            // caller's stream always finds CUs whose registers and LDS are not held by long weight-gradient blocks.  0 = all CUs.
-            static const int side_cus = getenv("UNET_SIDE_CUS") ? atoi(getenv("UNET_SIDE_CUS")) : 0;
-            static const int side_cu0 = getenv("UNET_SIDE_CU_FIRST") ? atoi(getenv("UNET_SIDE_CU_FIRST")) : 0;
-            const bool masked = side_cus > 0 && create_cu_range_stream(device, side_cu0, side_cus, &p->side);
-            if (!masked) HIP_OK(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, pr_least));
+            // (a CU-masked side stream -- unet_plan_side_cu_range -- measured slower than occupancy politeness: profiles/r10d_ab_cu_mask.txt)
+            HIP_OK(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, pr_least));
             // the plan's events only order its two streams on ONE device: no host ever waits on them, so the system-scope fence a
-            // default event performs when it is recorded (cache write-back for host visibility) is not needed (UNET_EVENT_SYSFENCE=1 keeps it)
-            const unsigned evf = hipEventDisableTiming | ((getenv("UNET_EVENT_SYSFENCE") && getenv("UNET_EVENT_SYSFENCE")[0] == '1') ? 0u : hipEventDisableSystemFence);
+            // default event performs when it is recorded (cache write-back for host visibility) is not needed
+            const unsigned evf = hipEventDisableTiming | hipEventDisableSystemFence;
             HIP_OK(hipEventCreateWithFlags(&p->ev_fork, evf));
             HIP_OK(hipEventCreateWithFlags(&p->ev_join, evf));
             HIP_OK(hipEventCreateWithFlags(&p->ev_pack, evf));
-            HIP_OK(hipEventCreateWithFlags(&p->ev_deep, evf));
             HIP_OK(hipEventCreateWithFlags(&p->ev_packd, evf));
             HIP_OK(hipMalloc((void**)&p->segs_dev, segs.size() * sizeof(SgdSeg)));
             HIP_OK(hipMemcpy(p->segs_dev, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
@@ -1361,8 +1314,7 @@ int unet_forward_loss_mode(const unet_plan* p, const float* const* params, float
         bool prepared = false;
         // ONE fork for all coarse levels, taken when the last of them (level 1) has its head: an event record costs the caller's stream
         // ~6 us, the coarse levels' loss kernels ~0.1 ms in all, and the full-resolution decoder level that follows (~0.25 ms) covers them
-        // (UNET_LOSS_FORK_PER_LEVEL: a fork per level as in round 2)
-        static const bool per_level = getenv("UNET_LOSS_FORK_PER_LEVEL") != nullptr;
+        constexpr bool per_level = false;     // (a fork per level, as in round 2, measured no faster: profiles/r07_ab_stream_knobs.txt)
         std::function<void(int)> on_head = [&](int level) {
             if (level < 1 || (size_t)level >= lr.levels()) return;
             if (!per_level && level != 1) return;

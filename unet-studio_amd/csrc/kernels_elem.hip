@@ -703,8 +703,7 @@ __global__ void __launch_bounds__(256) k_norm_finalize_apply8(const float* __res
     }
 }
 static inline bool fused_norm_ok(int dtype, int C, int nblk) {
-    static const bool off = getenv("UNET_NO_FUSED_FINALIZE") != nullptr;
-    return !off && dtype == 1 && C % 8 == 0 && C <= FUSED_MAX_C && 256 % (C / 8) == 0 && nblk <= FUSED_MAX_ROWS;
+    return dtype == 1 && C % 8 == 0 && C <= FUSED_MAX_C && 256 % (C / 8) == 0 && nblk <= FUSED_MAX_ROWS;
 }
 static inline int64_t fused_vpb(int C, int64_t S) {
     const int64_t nv = 256 / (C / 8);

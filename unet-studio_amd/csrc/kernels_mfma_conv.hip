@@ -1101,8 +1101,7 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z(MfmaConvArgs a, ZWork zw
 // sliding-window launcher: returns 0 if the geometry does not qualify, else gridDim.x
 static int launch_conv_z(const MfmaConvArgs& a0, hipStream_t s) {
     const ConvGeom& g = a0.g;
-    static const bool off = getenv("UNET_NO_CONV_Z") != nullptr;
-    if (off || g.Cin != 32 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
+    if (sliding_window_off() || g.Cin != 32 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
     for (int k = 0; k < 2; ++k)   // outputs are addressed with 31-bit byte offsets through a buffer descriptor
         if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return 0;
     ZWork zw;
@@ -1148,8 +1147,7 @@ static int launch_cfg(const MfmaConvArgs& a0, hipStream_t s) {   // returns grid
     const int tiles = a.tiles_x * a.tiles_y * a.tiles_z, gy = a.g.Cout / (16 * NT);
     // resident blocks per CU the LDS footprint allows, as a power of two (768-block grids measured 25 % slower than 512 / 1024)
     constexpr int bpc = (lds <= 40 * 1024 && NW == 4) ? 4 : 2;
-    static const int bpc_env = getenv("UNET_CONV_BPC") ? atoi(getenv("UNET_CONV_BPC")) : 0;   // experiment knob
-    int gx = (bpc_env > 0 ? bpc_env : bpc) * 256 / gy;
+    int gx = bpc * 256 / gy;
     if (gx < 1) gx = 1;
     if (gx > tiles) gx = tiles;
     dim3 grid((unsigned)gx, (unsigned)gy);
@@ -1170,13 +1168,10 @@ template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> stati
     int ntt = a.g.Cout / 16;
     if constexpr (SC) {   // scatter kinds always have ntt % 4 == 0 (rows = 8 * C, C % 16 == 0)
         // small volumes (the 4^3 / 8^3 levels: 1..8 tiles): fewer row tiles per block, so that more blocks stream the filter
-        // (UNET_SC_NT=4 restores four row tiles per block everywhere)
-        static const int sc_nt = getenv("UNET_SC_NT") ? atoi(getenv("UNET_SC_NT")) : 0;
         int tiles = ((a.g.Wo + BX - 1) / BX) * ((a.g.Ho + BY - 1) / BY) * ((a.g.Do + BZ - 1) / BZ);
         int nt = 4;
         if constexpr (BX <= 8) {
             while (nt > 1 && (int64_t)tiles * (ntt / nt) < 256) nt >>= 1;
-            if (sc_nt > 0) nt = sc_nt;
             if (nt == 1) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, true>(a, s);
             if (nt == 2) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, true>(a, s);
         }
@@ -1189,9 +1184,8 @@ template <int S, int KD, int PAD, int BZ, int BY, int BX, int CK, bool SC> stati
         while (nt > 1 && KSTEPS * nt > 32) nt >>= 1;            // keep the chunk's filter fragments LDS-resident
         while (nt > 1 && (int64_t)tiles * (ntt / nt) < 256) nt >>= 1;
         // a single 16-channel chunk (the dgrad of decode0.0, 16 -> 32 at full resolution): two one-row-tile blocks, each staging the
-        // filter slice once, beat one two-row-tile block (UNET_NT_SINGLE16=0 restores the latter)
-        static const bool single16 = !(getenv("UNET_NT_SINGLE16") && getenv("UNET_NT_SINGLE16")[0] == '0');
-        if (single16 && CK == 16 && a.g.Cin == 16 && nt == 2 && S == 1 && KD == 3) nt = 1;
+        // filter slice once, beat one two-row-tile block
+        if (CK == 16 && a.g.Cin == 16 && nt == 2 && S == 1 && KD == 3) nt = 1;
         if (nt == 4) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 4, false>(a, s);
         if (nt == 2) return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 2, false>(a, s);
         return launch_cfg<S, KD, PAD, BZ, BY, BX, CK, 1, false>(a, s);
@@ -1204,8 +1198,7 @@ static int tile_count(const ConvGeom& g, Tile t) { return ((g.Wo + t.bx - 1) / t
 // small volumes (the deep levels) get small tiles so that tiles x row-tiles still covers the chip
 static bool small_s1k3(const ConvGeom& g, int CK) {   // few big tiles: the volume is small, use k_mfma_conv_small (CK 32)
     Tile big = g.Wo >= 12 ? (CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16}) : (g.Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4});
-    static const int below = getenv("UNET_SMALL_BELOW") ? atoi(getenv("UNET_SMALL_BELOW")) : 256;   // experiment knob
-    return (int64_t)tile_count(g, big) * (g.Cout / 16) < below;
+    return (int64_t)tile_count(g, big) * (g.Cout / 16) < 256;
 }
 static Tile tile_s1k3(const ConvGeom& g, int CK) {
     Tile big = g.Wo >= 12 ? (CK == 32 ? Tile{4, 4, 16} : Tile{4, 8, 16}) : (g.Wo > 4 ? Tile{4, 8, 8} : Tile{4, 4, 4});
@@ -1251,8 +1244,7 @@ static int launch_s1k3(const MfmaConvArgs& a, int CK, hipStream_t s) {
 static Tile tile_s2k3(int Wo) { return Wo >= 12 ? Tile{2, 4, 16} : (Wo > 4 ? Tile{2, 4, 8} : Tile{4, 4, 4}); }
 // stride-2 forward onto 8^3 voxels or fewer: 32-channel chunks (half as many pipeline stages; the 64-voxel tile's halo is 70 KB)
 static bool s2_fwd_ck32(const ConvGeom& g) {
-    static const bool off = getenv("UNET_S2_FWD_CK16") != nullptr;
-    return !off && g.stride == 2 && g.ks == 3 && g.Cin % 32 == 0 && g.Wo <= 8;
+    return g.stride == 2 && g.ks == 3 && g.Cin % 32 == 0 && g.Wo <= 8;
 }
 static int launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 (halo of a stride-2 tile is 8x the output tile); small volumes: 32
     if (s2_fwd_ck32(a.g)) return a.g.Wo > 4 ? launch_nt<2, 3, 1, 2, 4, 8, 32, false>(a, s) : launch_nt<2, 3, 1, 4, 4, 4, 32, false>(a, s);
@@ -1262,8 +1254,7 @@ static int launch_s2k3(const MfmaConvArgs& a, hipStream_t s) {   // CK 16 (halo 
 }
 // conv_trans dgrad onto 8^3 voxels or fewer: 32-channel chunks (half as many pipeline stages; the 64-voxel tile's halo is 49 KB)
 static int convt_dgrad_ck(int cout_fwd, int coarseW) {
-    static const bool off = getenv("UNET_CONVT_DGRAD_CK16") != nullptr;
-    return (!off && cout_fwd % 32 == 0 && coarseW <= 8) ? 32 : 16;
+    return (cout_fwd % 32 == 0 && coarseW <= 8) ? 32 : 16;
 }
 static void launch_s2k2(const MfmaConvArgs& a, hipStream_t s) {   // conv_trans dgrad, CK 16 (small volumes: 32)
     if (convt_dgrad_ck(a.g.Cin, a.g.Wo) == 32) {
@@ -1436,8 +1427,8 @@ bool conv_first_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc* src,
 int conv_first_mfma_blocks(const ConvGeom& g) {
     int tiles = ((g.W + 15) / 16) * ((g.H + 7) / 8) * ((g.D + 3) / 4);
     // 73 VGPRs (Cout 16) allow 6 blocks per CU; the kernel is a per-wave latency chain (LDS gathers -> MFMA -> store), so the grid, not
-    // the registers, set its occupancy at the round-2 value of 512 (UNET_CONV_FIRST_BLOCKS: experiment knob)
-    static const int want = getenv("UNET_CONV_FIRST_BLOCKS") ? atoi(getenv("UNET_CONV_FIRST_BLOCKS")) : 512;
+    // the registers, set its occupancy at the round-2 value of 512
+    constexpr int want = 512;
     return tiles < want ? tiles : want;
 }
 int launch_conv_first_mfma(const ConvGeom& g, const SrcDesc* src, const float* w, const float* bias, void* out, float* stats_partial,

@@ -501,8 +501,7 @@ __global__ void __launch_bounds__(256, 2) k_mfma_conv_z32(MfmaConvArgs a, ZWork 
 
 int launch_conv_z32(const MfmaConvArgs& a0, hipStream_t s) {
     const ConvGeom& g = a0.g;
-    static const bool off = getenv("UNET_NO_CONV_Z32") != nullptr;     // falls back to k_mfma_conv_z (register-staged planes, hand-placed waits)
-    if (off || g.Cin != 32 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
+    if (sliding_window_off() || g.Cin != 32 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return 0;
     for (int k = 0; k < 2; ++k)
         if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return 0;
     if (a0.nout > 1 && a0.outC[0] % 16) return 0;
@@ -529,8 +528,7 @@ int launch_conv_z32(const MfmaConvArgs& a0, hipStream_t s) {
 
 bool conv_z16_applies(const MfmaConvArgs& a0) {
     const ConvGeom& g = a0.g;
-    static const bool off = getenv("UNET_NO_CONV_Z16") != nullptr;
-    if (off || g.Cin != 16 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return false;
+    if (sliding_window_off() || g.Cin != 16 || g.ks != 3 || g.stride != 1 || g.Wo < 12 || g.Do < 8 || g.D != g.Do || g.H != g.Ho || g.W != g.Wo) return false;
     if (g.Cout != 16 && g.Cout != 32) return false;
     for (int k = 0; k < 2; ++k)   // outputs are addressed with 31-bit byte offsets through a buffer descriptor
         if (a0.out[k] && (size_t)a0.oD * a0.oH * a0.oW * a0.outC[k] * 2 >= ((size_t)1 << 31)) return false;
@@ -543,9 +541,8 @@ int launch_conv_z16(const MfmaConvArgs& a0, hipStream_t s) {
     ZWork zw;
     zw.cols_x = (g.Wo + 15) / 16; zw.cols_y = (g.Ho + 7) / 8;
     const int cols = zw.cols_x * zw.cols_y;
-    static const int want_env = getenv("UNET_Z16_BLOCKS") ? atoi(getenv("UNET_Z16_BLOCKS")) : 0;
     const int gy = g.Cout / 16;                        // one row tile per block (two row tiles: 256 VGPRs and spills)
-    const int want = (want_env > 0 ? want_env : 512) / gy;    // two blocks per CU in total
+    const int want = 512 / gy;                         // two blocks per CU in total
     int nseg = (want + cols - 1) / cols;
     if (nseg < 1) nseg = 1;
     int zlen = (g.Do + nseg - 1) / nseg;

@@ -245,10 +245,9 @@ static int f32_fwd_variant(const ConvGeom& g, const SrcDesc* src) {
     const bool wide = g.Cout % 32 == 0 && tiles * (g.Cout / 32) >= 512;
     // levels with few tiles (32^3 and below in the default architecture): a 4x4x16 tile with 16-channel chunks -- twice the blocks,
     // half the chunk passes (forward at 128^3: 8.4 -> 7.4 ms); the 128^3 layers are faster on the 4x8x16 / 8-channel form
-    // (0.62 vs 0.68 ms for 32->16).  UNET_F32_TILE=0 keeps the large tile everywhere, =1 forces the small one.
-    static const int knob = getenv("UNET_F32_TILE") ? atoi(getenv("UNET_F32_TILE")) : -1;
+    // (0.62 vs 0.68 ms for 32->16; profiles/r09_forward_kernel_stats.csv)
     const bool few = tiles * (g.Cout / 16) < 2048;
-    if (g.stride == 1 && !wide && g.Cin % 16 == 0 && src[0].C % 16 == 0 && (knob == 1 || (knob < 0 && few))) return 2;
+    if (g.stride == 1 && !wide && g.Cin % 16 == 0 && src[0].C % 16 == 0 && few) return 2;
     if (g.stride == 1) return wide ? 1 : 0;
     // stride 2: 4x2x16 outputs from a 9x5x33 halo in 8-channel chunks (0.37 ms per forward faster than 4x4x16 with 4-channel chunks,
     // whose halo forced twice the chunk passes)

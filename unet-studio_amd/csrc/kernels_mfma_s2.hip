@@ -322,10 +322,7 @@ __global__ void __launch_bounds__(256, 2) k_s2_scatter(S2ScatterArgs a) {
 }
 
 // ---- launch ----
-static bool s2_off() {
-    static const bool off = getenv("UNET_NO_S2_KERNELS") != nullptr;     // fall back to k_mfma_conv_p for every shape
-    return off;
-}
+static bool s2_off() { return sliding_window_off(); }     // UNET_NO_SLIDING_WINDOW: k_mfma_conv_p for every shape
 static void s2_work(S2ScatterArgs& a, int gy, int* gx) {
     a.cols_x = (a.cW + 15) / 16; a.cols_y = (a.cH + 1) / 2;
     const int cols = a.cols_x * a.cols_y;

@@ -708,8 +708,7 @@ bool conv_first_wgrad_mfma_supported(int dtype, const ConvGeom& g, const SrcDesc
 }
 static int first_wgrad_blocks(const ConvGeom& g) {
     int tiles = ((g.W + 31) / 32) * ((g.H + 7) / 8) * ((g.D + 1) / 2);
-    static const int want = getenv("UNET_WGRAD_FIRST_BLOCKS") ? atoi(getenv("UNET_WGRAD_FIRST_BLOCKS")) : 512;   // experiment knob
-    return tiles < want ? tiles : want;
+    return tiles < 512 ? tiles : 512;
 }
 size_t conv_first_wgrad_mfma_scratch_bytes(const ConvGeom& g) { return (size_t)first_wgrad_blocks(g) * (27 * g.Cout + g.Cout) * 4 + 256; }
 // dw += , db += (db may be null); scratch: conv_first_wgrad_mfma_scratch_bytes
@@ -755,8 +754,7 @@ struct WgradCfg { int bz, by, bx, pi, pj, nsplit, gy, direct, polite = 0; };
 // (Round 2 ran these as 64..128 blocks of 2x2 pairs with one LDS read pair in flight per MFMA, each writing a 110-KB slab tile:
 // 20..43 us per layer for < 0.3 % of the step's FLOPs.)
 static bool wgrad_direct_cfg(int kind, int bD, int bH, int bW, WgradCfg& c) {
-    static const bool off = getenv("UNET_NO_WGRAD_DIRECT") != nullptr;
-    if (off || bD != bH || bH != bW) return false;
+    if (bD != bH || bH != bW) return false;
     if (bW == 4) { c.bz = 4; c.by = 4; c.bx = 4; }
     else if (bW == 8 && kind == 0) { c.bz = 8; c.by = 8; c.bx = 8; }      // stride 1: the 10^3 halo of a 16-channel tile is 32 KB
     else if (bW == 8) { c.bz = 2; c.by = 8; c.bx = 8; }                   // stride 2 / conv_trans: halo planes of 17^2 / 16^2 voxels, 4 tiles along z
@@ -773,23 +771,19 @@ static WgradCfg wgrad_cfg(int kind, int Ca, int Cb, int bD, int bH, int bW) {
         c.pi = cat % 2 == 0 ? 2 : 1; c.pj = cbt % 2 == 0 ? 2 : 1;
         // One (ca, cb) pair per block with the 4 waves splitting K is what lets the next tile's loads ride in registers
         // (PREF); measured on the whole step: 5.15 ms with 2x2 pairs, 4.95 ms with single pairs at W >= 12.
-        static const int p11 = getenv("UNET_WGRAD_P11") ? atoi(getenv("UNET_WGRAD_P11")) : 1;   // experiment knob
-        if ((p11 == 1 && bW >= 12) || p11 == 3) { c.pi = 1; c.pj = 1; }
+        if (bW >= 12) { c.pi = 1; c.pj = 1; }
         if (bW >= 12) { c.bz = 2; c.by = 8; c.bx = 16; }
         else if (bW > 4) { c.bz = 4; c.by = 8; c.bx = 8; }
         else { c.bz = 4; c.by = 8; c.bx = 4; }
     } else {
         c.pi = 1; c.pj = cbt % 4 == 0 ? 4 : (cbt % 2 == 0 ? 2 : 1);
-        static const int ts12 = getenv("UNET_WGRAD_TS12") ? atoi(getenv("UNET_WGRAD_TS12")) : 0;   // experiment knob: single pairs (tap-split waves)
-        if (ts12 == 1 || (ts12 == 2 && cat * cbt <= 4)) c.pj = 1;
         if (bW >= 12) { c.bz = 2; c.by = 4; c.bx = 16; }
         else if (bW > 4) { c.bz = 2; c.by = 8; c.bx = 8; }
         else { c.bz = 4; c.by = 8; c.bx = 4; }
     }
     c.gy = (cat / c.pi) * (cbt / c.pj);
     int tiles = ((bW + c.bx - 1) / c.bx) * ((bH + c.by - 1) / c.by) * ((bD + c.bz - 1) / c.bz);
-    static const int target = getenv("UNET_WGRAD_BLOCKS") ? atoi(getenv("UNET_WGRAD_BLOCKS")) : 512;   // experiment knob: blocks per launch
-    int want = (kind == 0 ? 512 : target) / c.gy;
+    int want = 512 / c.gy;
     if (want < 1) want = 1;
     c.nsplit = tiles < want ? tiles : want;
     return c;

@@ -382,8 +382,7 @@ __global__ void __launch_bounds__(64 * WK * PA * PB, (WK * PA * PB) == 4 ? 2 : 2
 struct WgradZCfg { int bx, wk, pa, pb, by, cols_x, cols_y, nseg, zlen, gx, gy; };
 
 static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c, int polite = 0) {
-    static const bool off = getenv("UNET_NO_WGRAD_Z") != nullptr;
-    if (off || g.ks != 3 || g.stride != 1 || g.Cin % 16 || g.Cout % 16) return false;
+    if (sliding_window_off() || g.ks != 3 || g.stride != 1 || g.Cin % 16 || g.Cout % 16) return false;
     if (g.W < 24 || g.D < 4) return false;                 // narrower volumes: k_mfma_wgrad
     const int cat = g.Cin / 16, cbt = g.Cout / 16;
     c.bx = 32;
@@ -392,13 +391,11 @@ static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c, int polite = 0) {
     else if (cbt % 2 == 0) { c.pa = 1; c.pb = 2; c.wk = 4; }
     else { c.pa = 1; c.pb = 1; c.wk = 4; }
     // at 32^3 a 2x2-pair block leaves 128 blocks for the chip (4 footprint columns x 8 segments x 4 pair groups); single pairs give 512
-    // (step 3.22 -> 3.19 ms; at 64^3 no difference).  UNET_WZ_P11 = voxel count at or below which single pairs are used.
-    static const int p11_vox = getenv("UNET_WZ_P11") ? atoi(getenv("UNET_WZ_P11")) : 32768;
-    if (p11_vox > 0 && (int64_t)g.D * g.H * g.W <= (int64_t)p11_vox) { c.pa = 1; c.pb = 1; c.wk = 4; }
+    // (step 3.22 -> 3.19 ms; at 64^3 no difference)
+    if ((int64_t)g.D * g.H * g.W <= (int64_t)32768) { c.pa = 1; c.pb = 1; c.wk = 4; }
     else if (polite) {   // 4-wave blocks: a pair of tiles on one side where the channels allow it (one read of the other side serves both), 4 rows
-        static const bool pairs = getenv("UNET_WZ_POLITE_SINGLE") == nullptr;
-        if (pairs && cat % 2 == 0) { c.pa = 2; c.pb = 1; c.wk = 2; }
-        else if (pairs && cbt % 2 == 0) { c.pa = 1; c.pb = 2; c.wk = 2; }
+        if (cat % 2 == 0) { c.pa = 2; c.pb = 1; c.wk = 2; }
+        else if (cbt % 2 == 0) { c.pa = 1; c.pb = 2; c.wk = 2; }
         else { c.pa = 1; c.pb = 1; c.wk = 4; }
     }
     c.by = 2 * c.wk;
@@ -406,18 +403,14 @@ static bool wgrad_z_cfg(const ConvGeom& g, WgradZCfg& c, int polite = 0) {
     c.gy = (cat / c.pa) * (cbt / c.pb);
     const int cols = c.cols_x * c.cols_y;
     const int nwaves = c.wk * c.pa * c.pb;
-    static const int want_env = getenv("UNET_WZ_BLOCKS") ? atoi(getenv("UNET_WZ_BLOCKS")) : 0;   // experiment knob: blocks per launch
-    static const int want8_env = getenv("UNET_WZ_BLOCKS8") ? atoi(getenv("UNET_WZ_BLOCKS8")) : 0;   // the same for the 8-wave pair blocks
-    static const int wantp_env = getenv("UNET_WZ_BLOCKSP") ? atoi(getenv("UNET_WZ_BLOCKSP")) : 0;   // ... and for polite launches
     // ~8 waves per CU in total; a polite launch is resident in one round at one block per CU
-    int want = nwaves == 4 ? (polite ? (wantp_env > 0 ? wantp_env : 256) : (want_env > 0 ? want_env : 512))
-                           : (want8_env > 0 ? want8_env : (want_env > 0 ? want_env : 256));
+    int want = nwaves == 4 ? (polite ? 256 : 512) : 256;
     want /= c.gy;
     if (want < 1) want = 1;
     int nseg = (want + cols - 1) / cols;
     if (nseg < 1) nseg = 1;
     int zlen = (g.D + nseg - 1) / nseg;
-    if (zlen < 4 && want_env <= 0) zlen = 4;               // >= 4 planes of work per 2 warm-up steps
+    if (zlen < 4) zlen = 4;                                // >= 4 planes of work per 2 warm-up steps
     if (zlen > g.D) zlen = g.D;
     c.nseg = (g.D + zlen - 1) / zlen; c.zlen = zlen;
     c.gx = cols * c.nseg;
@@ -445,17 +438,11 @@ static void launch_wz(const WgradZArgs& a, const WgradZCfg& c, hipStream_t s, in
     constexpr int RPK = 32 / BX, BY = 2 * WK * RPK, HY = BY + 2, HX = BX + 2;
     constexpr int lds = 2 * (PA * HY * HX * 32 + PB * BY * BX * 32);
     static_assert(lds <= 80 * 1024, "LDS budget");
+    static_assert(WK * PA * PB == 8, "the 4-wave work splits run on k_mfma_wgrad_zd");
     static std::atomic<uint64_t> attr_done{0};
-    const int lds_launch = (WK * PA * PB == 4) ? polite_lds(lds, polite) : lds;
-    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, polite_lds(lds, 1));   // once per kernel: the polite size
-    static const bool dbg = getenv("UNET_WZ_DEBUG") != nullptr;
-    if (dbg) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, 64 * WK * PA * PB, lds);
-        fprintf(stderr, "k_mfma_wgrad_z<%d,%d,%d,%d>: grid %d x %d, %d threads, %d B LDS, zlen %d, occupancy API: %d blocks/CU\n", BX, WK, PA, PB,
-                c.gx, c.gy, 64 * WK * PA * PB, lds, c.zlen, nb);
-    }
-    k_mfma_wgrad_z<BX, WK, PA, PB><<<dim3((unsigned)c.gx, (unsigned)c.gy), 64 * WK * PA * PB, lds_launch, s>>>(a);
+    set_max_lds_once(attr_done, (const void*)k_mfma_wgrad_z<BX, WK, PA, PB>, lds);
+    (void)polite;      // 8-wave blocks are never launched politely (wgrad_z_cfg gives polite launches a 4-wave split)
+    k_mfma_wgrad_z<BX, WK, PA, PB><<<dim3((unsigned)c.gx, (unsigned)c.gy), 64 * WK * PA * PB, lds, s>>>(a);
 }
 
 // Launches the kernel only: slab [gx][Cout][Cin][27] (+ bias_slab [gx][Cout] when want_bias) at `scratch`; returns the number of
@@ -470,14 +457,11 @@ int launch_mfma_wgrad_z(const ConvGeom& g, const SrcDesc* src, int nsrc, const v
     a.slab = (float*)scratch;
     a.bias_slab = want_bias ? a.slab + (size_t)c.gx * 27 * g.Cin * g.Cout : nullptr;
     a.cols_x = c.cols_x; a.cols_y = c.cols_y; a.nseg = c.nseg; a.zlen = c.zlen;
-    static const bool noslab = getenv("UNET_WZ_NOSLAB") != nullptr;   // timing experiment only (results are wrong): skip the slab stores
-    if (noslab) a.nseg = -c.nseg;
-    if (c.wk == 2 && c.pa == 2 && c.pb == 1) launch_wz<32, 2, 2, 1>(a, c, s, polite);
-    else if (c.wk == 2 && c.pa == 1 && c.pb == 2) launch_wz<32, 2, 1, 2>(a, c, s, polite);
-    else if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s, polite);
+    // the 4-wave work splits (polite launches, <= 32^3 volumes, odd tile counts) run with LDS-DMA staging: kernels_mfma_wgrad_zd.hip
+    if (launch_wgrad_zd(g, src, nsrc, dy, a.slab, a.bias_slab, c.wk, c.pa, c.pb, c.cols_x, c.cols_y, c.nseg, c.zlen, c.gx, c.gy, s, polite)) return c.gx;
+    if (c.pa == 2 && c.pb == 2) launch_wz<32, 2, 2, 2>(a, c, s, polite);
     else if (c.pa == 2) launch_wz<32, 4, 2, 1>(a, c, s, polite);
-    else if (c.pb == 2) launch_wz<32, 4, 1, 2>(a, c, s, polite);
-    else launch_wz<32, 4, 1, 1>(a, c, s, polite);
+    else launch_wz<32, 4, 1, 2>(a, c, s, polite);
     return c.gx;
 }
 

@@ -24,10 +24,17 @@ inline void set_max_lds_once(std::atomic<uint64_t>& done, const void* fn, int by
 // blocks: one wave per SIMD, >= 256 VGPRs per SIMD and ~77 KB of LDS left for the kernels of the caller's stream.  Measured (time line of
 // a step, profiles/r10a_stretch.txt): at two blocks per CU a 240-VGPR weight-gradient kernel fills every SIMD's register file, and a
 // 5-us norm kernel of the caller's stream that became ready beside it waited 64 us for the first block to leave.
-// UNET_SIDE_POLITE=<bytes> overrides the request (0 = off).
 inline int polite_lds(int lds, int polite) {
-    static const int want = getenv("UNET_SIDE_POLITE") ? atoi(getenv("UNET_SIDE_POLITE")) : 83000;
+    constexpr int want = 83000;
     return (polite && want > lds) ? want : lds;
+}
+// UNET_NO_SLIDING_WINDOW=1 (read once per process): every convolution, conv_trans and weight-gradient shape runs on the halo-tile kernels
+// k_mfma_conv_p / k_mfma_conv_small / k_mfma_wgrad instead of the sliding-window kernels whose vector-memory waits are counted by hand
+// (k_mfma_conv_z, _z16, _z32, k_mfma_wgrad_z, _zd, k_s2_scatter, k_s2_gather, k_s2_wgrad) -- the documented fallback named by the build
+// check (tools/check_asm_loads.py), and the way the halo-tile kernels stay under test (tests/test_gpu_parity.py runs the op cases with it).
+inline bool sliding_window_off() {
+    static const bool off = getenv("UNET_NO_SLIDING_WINDOW") != nullptr;
+    return off;
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -90,5 +97,8 @@ struct ZWork { int nseg, zlen, cols_x, cols_y; };
 int launch_conv_z16(const MfmaConvArgs& a, hipStream_t s);
 bool conv_z16_applies(const MfmaConvArgs& a);               // the geometry test of launch_conv_z16 alone
 int launch_conv_z32(const MfmaConvArgs& a, hipStream_t s);     // the same for a single 32-channel chunk
+// kernels_mfma_wgrad_zd.hip: k_mfma_wgrad_z's 4-wave configurations with LDS-DMA staging (called by launch_mfma_wgrad_z with its own work split)
+bool launch_wgrad_zd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* dy, float* slab, float* bias_slab, int wk, int pa, int pb, int cols_x,
+                     int cols_y, int nseg, int zlen, int gx, int gy, hipStream_t s, int polite);
 
 }  // namespace unet

@@ -246,7 +246,8 @@ def scan_dma_cfg(body):
     results = {}      # (from kind, to kind) -> set of (dma, store)
     other = []
     sys.setrecursionlimit(100000)
-    for start, n0 in wait_at.items():
+    starts = list(wait_at.items()) + [(-1, 0)]      # the kernel's entry counts as a vmcnt(0): nothing is in flight there
+    for start, n0 in starts:
         seen = set()
         stack = [(start + 1, 0, 0)]
         while stack:
@@ -313,6 +314,10 @@ def main(which, path, out_json=None):
     elif which == "conv_zdma":
         bodies = kernel_bodies(text, "k_mfma_conv_z16") + kernel_bodies(text, "k_mfma_conv_z32")
         mode = "dma"
+    elif which == "wgrad_zd":
+        # kernels_mfma_wgrad_zd.hip: P DMA pieces per wave and step, no stores in the loop, one hand-counted wait vmcnt((PF - 1) P)
+        bodies = kernel_bodies(text, "k_mfma_wgrad_zdI")
+        mode = "dma"
     elif which == "s2dma":
         # kernels_mfma_s2.hip: the same LDS-DMA discipline (P pieces + S stores per wave and step, one hand-counted wait)
         bodies = kernel_bodies(text, "k_s2_scatter") + kernel_bodies(text, "k_s2_gather")
@@ -325,7 +330,7 @@ def main(which, path, out_json=None):
     for sym, body in bodies:
         meta = metadata(text, sym)
         if mode == "dma":
-            errors, st = scan_dma_cfg(body) if which == "s2dma" else scan_dma(body)     # (spills outside the hand-counted steps are harmless here: the steps are checked instruction by instruction)
+            errors, st = scan_dma_cfg(body) if which in ("s2dma", "wgrad_zd") else scan_dma(body)     # (spills outside the hand-counted steps are harmless here: the steps are checked instruction by instruction)
             st.update({"asm_loads": st.get("dma_pieces_per_step", 0), "buffer_store_dwordx2": st.get("stores_per_step", 0)})
         else:
             errors, st = scan(body, mode)
@@ -333,7 +338,7 @@ def main(which, path, out_json=None):
                 if meta.get(key) != 0:
                     errors.append("%s = %s (must be 0)" % (key, meta.get(key)))
         if mode == "dma":
-            if which == "s2dma" and (meta.get(".vgpr_spill_count") or meta.get(".private_segment_fixed_size")):
+            if which in ("s2dma", "wgrad_zd") and (meta.get(".vgpr_spill_count") or meta.get(".private_segment_fixed_size")):
                 errors.append("scratch in use: vgpr spills %s, private segment %s" % (meta.get(".vgpr_spill_count"), meta.get(".private_segment_fixed_size")))
         elif which == "conv_z":
             if st["asm_loads"] != 12:

@@ -54,19 +54,19 @@ class Trainer:
         if comm is not None:
             self.rank, self.world_size = comm.rank, comm.world
         # world_size > 1: start the all-reduce of every finished gradient bucket under the rest of the backward
-        self.overlap = os.environ.get("UNET_NO_OVERLAP") is None
+        self.overlap = True        # attribute (tests set it False: one all-reduce after the backward)
         # micro-steps 2.. of a step skip the filter repack (UNET_MODE_PACKS_CURRENT); models without the keyword (test stand-ins) do not
-        self.packs_reuse = os.environ.get("UNET_NO_PACK_REUSE") is None and hasattr(model, "_run_forward_loss")
+        self.packs_reuse = hasattr(model, "_run_forward_loss")
         # micro-steps of one optimizer step in flight on this GPU at a time (UNET_MICRO_IN_FLIGHT; default 1 = one after the other:
         # measured on MI355X at 128^3 bf16, batch 8: 2.99 ms per sample sequentially, 3.76 ms with two in flight -- kernels of two
         # samples that share the chip thrash each other's L2 patches and LDS occupancy)
         self.in_flight = max(1, int(os.environ.get("UNET_MICRO_IN_FLIGHT", "1")))
         # the engine writes the first micro-step's {total, ce, dice, mse} straight into the step's statistics (no zeroing launch, no add)
-        # UNET_PACK_AFTER_UPDATE=1 (experiment): the filter packs are made right behind the update, on the caller's stream, instead of by
-        # the next step's forward on the side stream beside its first kernels
-        self.pack_after_update = os.environ.get("UNET_PACK_AFTER_UPDATE") is not None and hasattr(model, "pack_filters")
+        # pack_after_update (attribute, default off: measured neutral): the filter packs are made right behind the update, on the caller's
+        # stream, instead of by the next step's forward on the side stream beside its first kernels
+        self.pack_after_update = False
         self._packed_size, self._packed_version = None, None
-        self.stats_direct = hasattr(model, "_run_forward_loss") and os.environ.get("UNET_NO_STATS_DIRECT") is None
+        self.stats_direct = hasattr(model, "_run_forward_loss")
         self._lanes, self._gbufs, self._gptrs = None, [], []
         self.cur_epoch = 0
         model.train()

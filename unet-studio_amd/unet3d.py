@@ -14,7 +14,7 @@ from . import engine as E
 _DT = {"fp32": E.DTYPE_F32, "f32": E.DTYPE_F32, "float32": E.DTYPE_F32, "bf16": E.DTYPE_BF16, "bfloat16": E.DTYPE_BF16}
 
 
-_NO_FUSED_LOSS = __import__("os").environ.get("UNET_NO_FUSED_LOSS") is not None   # experiment switch: forward and loss as two engine calls
+_NO_FUSED_LOSS = False   # (forward and loss as two engine calls: test_fused_forward_loss_equals_the_two_calls compares them through the ABI)
 
 
 def _stream_ptr(device):
