@@ -6,7 +6,7 @@ export TMPDIR=/tmp UNET_NO_SIDE_STREAM=1
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $R/gpurun_out/step_$c
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/step_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile --no-kernels --batch 0 > $R/gpurun_out/step_$c.log 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/step_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-profile --no-kernels --no-cpp-host --batch 0 > $R/gpurun_out/step_$c.log 2>&1
 done
 python3 - "$R" <<'PY'
 import csv, glob, json, sys, collections, re

@@ -316,6 +316,34 @@ def _check_grad_samples(m, d, big, tol, min_numel=0):
     return worst
 
 
+def _check_grad_samples_l2(m, d, big, tol, tol_el, min_numel=0, min_samples=32):
+    """the strided sample of every gradient tensor as a VECTOR: relative L2 distance to the fixture's sample (a permuted tap or a
+    transposed channel pair gives ~1.4; rounding noise averages over the sample's elements) where the sample holds >= min_samples elements,
+    else every sampled element against tol_el of the tensor's max -> (worst L2 distance, worst single element over all tensors)"""
+    off, worst, worst_el, rows = 0, 0.0, 0.0, []
+    for i, g in enumerate(m.grads()):
+        smp = g.flatten()[::GRAD_SAMPLE_STRIDE].cpu().numpy().astype(np.float64)
+        want = d["grad_sample"][off:off + smp.size].astype(np.float64)
+        off += smp.size
+        if not big[i] or g.numel() < min_numel:
+            continue
+        err = float(np.linalg.norm(smp - want) / max(np.linalg.norm(want), 1e-30))
+        el = float(np.abs(smp - want).max()) / float(d["grad_absmax"][i])
+        rows.append((i, smp.size, err, el))
+        worst_el = max(worst_el, el)
+        if smp.size >= min_samples:
+            worst = max(worst, err)
+    assert off == d["grad_sample"].size
+    print("  gradient samples (parameter, sampled elements, relative L2 of the sample, worst element / tensor max):",
+          [(i, n, "%.2e" % e, "%.2e" % x) for i, n, e, x in sorted(rows, key=lambda r: -r[2])[:6]])
+    for i, n, e, x in rows:
+        if n >= min_samples:
+            assert e < tol, "gradient sample vector of parameter %d (%d sampled elements): relative L2 distance %.3e" % (i, n, e)
+        else:
+            assert x < tol_el, "gradient sample of parameter %d (%d sampled elements): %.3e of the tensor's max" % (i, n, x)
+    return worst, worst_el
+
+
 def _logit_stride(n, level):   # = tests/golden/make_golden.py:logit_stride
     side, st = n >> level, 1
     while side // st > 16:
@@ -406,7 +434,7 @@ def test_default_arch_bf16_against_the_bf16_storage_oracle(golden_dir, size):
     inside a layer and the roundings it flips, so the bounds are several times tighter than against the fp32 reference
     (test_default_arch_128_bf16_against_golden: 4e-2 / 8e-2 logits, 0.4 of a tensor's max on gradient samples): logits 1e-2 at the two
     finest levels and 2e-2 below, loss 2e-3, filter-gradient norms 3e-2 (measured 1.4e-2), sampled elements of every gradient tensor of >= 1024
-    elements 0.2 of the tensor's max (measured 7e-2 .. 1.3e-1), and the small tensors (norm scales / shifts, biases: < 1024 elements) by their norm, 0.15."""
+    elements as a sample vector, relative L2 0.3 (measured 0.15-0.23), and the small tensors (norm scales / shifts, biases: < 1024 elements) by their norm, 0.15."""
     d = np.load(os.path.join(golden_dir, "default_arch_%d_bf16.npz" % size))
     n = int(d["n"])
     torch.manual_seed(0)
@@ -449,13 +477,16 @@ def test_default_arch_bf16_against_the_bf16_storage_oracle(golden_dir, size):
     # by the time the gradient has crossed the network, and the sums cancel to about a tenth of their terms' random-walk size (measured:
     # 8.8e-2 on encode0.4.weight at 128^3, 7.7e-2 on encode1.4.bias at 64^3).  A wrong statistic (mean / rstd / a dropped term) is off by O(1).
     assert rel_l2[small].max() < 0.15, "gradient norm of parameter %d: %.3e" % (int(order_s[0]), rel_l2[small].max())
-    # sampled elements of the filters' gradients: measured 7e-2 .. 1.3e-1 of the tensor's max, depending on which kernel variant sums in
-    # which order (9.1e-2 at 128^3 and 6.6e-2 at 64^3 on encode0.3.weight -- every element a sum over the whole volume of products of two
-    # noisy bf16 tensors --, 1.27e-1 at 64^3 on a 16^3-level filter after the weight gradients moved to LDS-DMA staging); the same tensors'
-    # NORMS agree to 1.4e-2.  (Against the fp32 reference the bound is 0.4.)  A permuted tap or transposed channel pair is off by O(1).
-    worst = _check_grad_samples(m, d, big, 0.2, min_numel=1024)
-    print("bf16 vs bf16-storage oracle at %d^3: logits %.3e, gradient norms %.3e, gradient samples %.3e of the tensor's max"
-          % (size, worst_logit, rel_l2[big].max(), worst))
+    # the strided sample of every filter gradient (>= 1024 elements; every 997th element) as a vector: relative L2 distance to the
+    # oracle's sample.  Measured 0.15 .. 0.23 on EVERY filter tensor, whether the sample holds 7 or 1775 elements -- i.e. it does not
+    # average out: with the synthetic sample's random labels a filter-gradient element is itself a random-walk sum over up to 2M voxels,
+    # and the ~0.5 % of rounding-flip noise each bf16 term carries moves every element by ~1/5 of its size, while the tensors' NORMS
+    # (asserted above) agree to 1.4e-2 and the per-kernel operator tests hold every element of every weight gradient to 1e-2.  Bound 0.3:
+    # a permuted tap or a transposed channel pair moves the sample vector by ~1.4.  Worst single elements: 7e-2 .. 1.4e-1 of the
+    # tensor's max (the bound against the fp32 reference is 0.4).
+    worst, worst_el = _check_grad_samples_l2(m, d, big, 0.3, 0.35, min_numel=1024, min_samples=1)
+    print("bf16 vs bf16-storage oracle at %d^3: logits %.3e, gradient norms %.3e, gradient sample vectors %.3e (relative L2), worst single "
+          "sampled element %.3e of its tensor's max" % (size, worst_logit, rel_l2[big].max(), worst, worst_el))
 
 
 def test_default_arch_64_fp32_elu_twin_gradient_samples(golden_dir):
