@@ -134,3 +134,38 @@ def test_hand_counted_kernels_passed_the_build_time_assembly_check():
         assert d["ok"] and d["kernels"] and all(k["ok"] for k in d["kernels"]), r
     dma = json.load(open(os.path.join(ROOT, "unet-studio_amd", "asm_loads_check_conv_zdma.json")))
     assert {k["planes_ahead"] for k in dma["kernels"]} == {5}
+
+
+def test_unet_hpp_keeps_the_reference_class_surface():
+    """include/unet.hpp is a drop-in for the reference's unet.hpp: every member the reference's callers use (SURVEY.md section 8b;
+    declarations of /root/reference/unet.hpp:13-70, normalised for white space) must still be declared with the same signature.  A
+    static check of the header's text -- compiling against the reference's callers needs TIPL and Qt, which this image does not have."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = re.sub(r"\s+", " ", open(os.path.join(root, "include", "unet.hpp")).read())
+    required = [
+        "struct UNet3dImpl : torch::nn::Module",
+        "int in_count = 1;", "int out_count = 1;",
+        "std::string architecture,preproc,postproc,orientation,fov_strategy,error_msg;",
+        "std::shared_ptr<torch::optim::SGD> optimizer;",
+        "std::vector<float> testing_errors,training_errors;",
+        "std::vector<unsigned int> single_component_label;",
+        "mutable std::mutex error_mutex;",
+        "auto get_training_errors(void) const", "auto get_testing_errors(void) const",
+        "voxel_size = {1.0f,1.0f,1.0f};", "dim = {192,224,192};",
+        "std::deque<torch::nn::Sequential> encoding,decoding,decoding_tail;",
+        "std::vector<torch::nn::Sequential> output;",
+        "int create_layer(torch::nn::Sequential& layers,const std::string& def, int in_c);",
+        "std::string get_info(void) const;",
+        "UNet3dImpl(void){}", "UNet3dImpl(int32_t in_count_,int32_t out_count_,std::string);",
+        "void copy_from(const UNet3dImpl& r);", "void add_gradient_from(const UNet3dImpl& r);",
+        "void create_optimizer(float learning_rate);",
+        "std::vector<torch::Tensor> forward(torch::Tensor inputTensor);",
+        "void set_requires_grad(bool req)", "virtual void train(bool on = true) override",
+        "void print_layers(void);", "torch::Device device(void) const",
+        "void prepare_for_inference(const torch::Device& device);",
+        "TORCH_MODULE_IMPL(UNet3d, UNet3dImpl);",
+    ]
+    missing = [r for r in required if re.sub(r"\s+", " ", r) not in text]
+    assert not missing, "include/unet.hpp no longer declares: %s" % missing
