@@ -929,8 +929,10 @@ def test_stride2_dgrad_statistics_epilogue_and_kernels_match_the_separate_pass_a
         assert np.abs(a1[nm] - a0[nm]).max() <= 5e-4 * np.abs(a0[nm]).max(), nm
     assert np.abs(g1 - g0).max() <= 5e-3 * np.abs(g0).max()
     # against the halo-tile kernels: same arithmetic in another summation order (fp32 accumulators, then bf16 roundings downstream)
+    # (floor of 1e-2 of the largest gradient: a conv bias in front of a norm has an analytically zero gradient -- both sides hold ~3e-5 of
+    # rounding noise there, of which only the size is comparable)
     for nm in a2:
-        assert np.abs(a1[nm] - a2[nm]).max() <= 2e-2 * max(np.abs(a2[nm]).max(), 1e-3 * np.abs(g2).max()), nm
+        assert np.abs(a1[nm] - a2[nm]).max() <= 2e-2 * max(np.abs(a2[nm]).max(), 1e-2 * np.abs(g2).max()), nm
 
 
 def test_halo_tile_kernels_still_match_the_oracle():
