@@ -1,0 +1,3 @@
+run() { env $1 timeout -k 10 200 python bench.py --no-cpu-baseline --no-kernels --batch 0 --no-cpp-host --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],4))"; }
+for rep in 1 2; do
+for e in "X=1" "UNET_X_HOLD_BELOW=16" "UNET_X_HOLD_BELOW=16,UNET_X_HOLD_FROM=32" "UNET_X_HOLD_FROM=32" "UNET_X_NO_WOM=1" "UNET_X_SCATTER_BLOCKS=1024" "UNET_X_SCATTER_BLOCKS=256" "UNET_X_GATHER_BLOCKS=1024" "UNET_X_GATHER_BLOCKS=256"; do run "$(echo $e | tr ',' ' ')"; done; done
