@@ -416,7 +416,12 @@ def test_default_arch_128_bf16_against_golden(golden_dir):
     m._run_backward(plan, ws, gouts)
     gl2 = np.array([float(g.double().norm()) for g in m.grads()])
     big = d["grad_l2"] > 1e-2 * d["grad_l2"].max()
-    assert np.allclose(gl2[big], d["grad_l2"][big], rtol=8e-2)
+    # norms of the filter gradients within 8 %; the 16..256-element norm parameters' (sums over up to 2M voxels of cancelling bf16 terms)
+    # within 15 %: between two valid kernel sets (sliding-window / halo-tile / split-K, profiles/r20_deep_vs_sliding_gradients.txt, r20_sliding_vs_halo_gradients.txt) such a
+    # norm moves by up to 5 % and this fixture's encode1.1.bias sits 4..9 % from the fp32 reference depending on the set
+    numel = np.array([g.numel() for g in m.grads()])
+    assert np.allclose(gl2[big & (numel >= 1024)], d["grad_l2"][big & (numel >= 1024)], rtol=8e-2)
+    assert np.allclose(gl2[big], d["grad_l2"][big], rtol=0.15)
     # bf16 engine: its measured element-wise error on the conv / conv_trans weights (>= 1024 elements).  The 16..256-element norm and
     # bias gradients are sums over up to 2M voxels of bf16-rounded, cancelling terms: one sampled element of such a tensor was 25 % of
     # the tensor's max away (their norms are bounded above); a permuted or transposed filter gradient is off by O(1) on every sample.
@@ -848,7 +853,11 @@ arch = ("conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu\n
         "conv16,ks3,stride1+norm,leaky_relu+conv16,ks3,stride1+norm,leaky_relu+conv6,ks1,stride1")
 if len(sys.argv) > 4 and sys.argv[4] == "default":
     arch = U.default_feature(6)
-m = U.UNet3d(1, 6, arch, device="cuda:0", dtype="bf16", seed=0)
+if len(sys.argv) > 4 and sys.argv[4] == "deep2":      # two levels of 32 / 64 channels: at 16^3 the coarse level is 8^3 (kernels_mfma_deep.hip)
+    arch = ("conv32,ks3,stride1+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu\n"
+            "conv64,ks3,stride2+norm,leaky_relu+conv64,ks3,stride1+norm,leaky_relu+conv_trans32,ks2,stride2\n"
+            "conv32,ks3,stride1+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu+conv6,ks1,stride1")
+m = U.UNet3d(1, 6, arch, device="cuda:0", dtype=sys.argv[5] if len(sys.argv) > 5 else "bf16", seed=0)
 x, t = U.SyntheticVolumes(1, 6, (n, n, n), "cuda:0", cache=2)(0)
 m.forward_backward(x, t)
 torch.cuda.synchronize()
@@ -858,7 +867,7 @@ json.dump([[nm, int(np.prod(s))] for nm, s in zip(plan.param_names, plan.param_s
 """
 
 
-def _grads_in_fresh_process(tmp_path, tag, n, env_extra, arch=""):
+def _grads_in_fresh_process(tmp_path, tag, n, env_extra, arch="", dtype="bf16"):
     """flat gradients of one forward + backward of a small bf16 network, computed in a fresh process (the engine reads its
     experiment switches once per process) -> (gradients, [(parameter name, element count)])"""
     import json
@@ -868,7 +877,7 @@ def _grads_in_fresh_process(tmp_path, tag, n, env_extra, arch=""):
     path = str(tmp_path / ("grads_%s.npy" % tag))
     env = dict(os.environ)
     env.update(env_extra)
-    out = subprocess.run([sys.executable, "-c", _BNSTATS_CHILD, root, path, str(n), arch], capture_output=True, text=True, timeout=300, env=env)
+    out = subprocess.run([sys.executable, "-c", _BNSTATS_CHILD, root, path, str(n), arch, dtype], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     return np.load(path), json.load(open(path + ".json"))
 
@@ -897,13 +906,14 @@ def test_norm_backward_statistics_in_the_dgrad_epilogue_match_the_separate_pass(
 
 
 def test_norm_backward_statistics_in_the_small_volume_dgrad_epilogue_match_the_separate_pass(tmp_path):
-    """The same epilogue in k_mfma_conv_small (the dgrads of the 16^3 and smaller levels; UNET_NO_DGRAD_BNSTATS_SMALL=1 keeps the
-    separate k_norm_bwd_stats8 launches): the default architecture at 32^3 has such layers from the 8^3 level down.  The first of them
+    """The same epilogue in k_mfma_conv_small (the dgrads of the 16^3 level -- 8^3 and below run on the split-K kernels of
+    kernels_mfma_deep.hip, which do the whole norm backward; UNET_NO_DGRAD_BNSTATS_SMALL=1 keeps the separate k_norm_bwd_stats8
+    launches): the default architecture at 64^3 has its 64-channel level at 16^3.  The first such layer
     in backward order is decode2.3's dgrad (statistics of decode2.1's norm): that norm's parameter gradients agree to summation-order
     noise, everything computed before it (and the heads, which read no dL/d(raw)) exactly; the rest is bounded loosely (bf16 roundings
     of du flip downstream)."""
-    g1, names = _grads_in_fresh_process(tmp_path, "small_fused", 32, {}, arch="default")
-    g0, _ = _grads_in_fresh_process(tmp_path, "small_separate", 32, {"UNET_NO_DGRAD_BNSTATS_SMALL": "1"}, arch="default")
+    g1, names = _grads_in_fresh_process(tmp_path, "small_fused", 64, {}, arch="default")
+    g0, _ = _grads_in_fresh_process(tmp_path, "small_separate", 64, {"UNET_NO_DGRAD_BNSTATS_SMALL": "1"}, arch="default")
     a1, a0 = _by_name(g1, names), _by_name(g0, names)
     assert np.abs(g1 - g0).max() > 0, "both runs took the same path: the switch did not reach the engine"
     for nm in a0:
@@ -933,6 +943,36 @@ def test_stride2_dgrad_statistics_epilogue_and_kernels_match_the_separate_pass_a
     # rounding noise there, of which only the size is comparable)
     for nm in a2:
         assert np.abs(a1[nm] - a2[nm]).max() <= 2e-2 * max(np.abs(a2[nm]).max(), 1e-2 * np.abs(g2).max()), nm
+
+
+def test_deep_level_split_k_kernels_match_the_halo_tile_kernels_in_the_network(tmp_path):
+    """kernels_mfma_deep.hip in the network: at the deep levels the contractions run split over K, finished by the block that arrives
+    last, with the norm layer behind the conv (forward: statistics, running statistics, activated copy) or in front of it (backward:
+    statistics, affine gradients, dL/d(raw)) in that epilogue.  UNET_NO_DEEP_KERNELS=1 keeps the halo-tile kernels and the separate norm
+    launches there.  A two-level network of 32 / 64 channels: at 8^3 its coarse level is 4^3 (the 27-tap kinds with both norm epilogues,
+    one dgrad accumulating into the skip gradient), at 16^3 it is 8^3 (the short kinds only: conv_trans forward / dgrad, stride-2 dgrad).
+    The two paths do the same arithmetic in another summation order and bf16 roundings downstream amplify that (these are tiny
+    volumes: a few % of a tensor's size), so each is measured against the fp32 ENGINE (other kernels, fp32 storage) on the same
+    sample: the new path's distance to it must be the old path's, tensor by tensor.  And the default architecture at 32^3 (levels 3..5:
+    4^3 x 128 channels ... 1^3 x 256, every shape of the path) is reproducible run to run: fixed summation order whichever block
+    arrives last."""
+    for n in (8, 16):
+        g1, names = _grads_in_fresh_process(tmp_path, "deep_on_%d" % n, n, {}, arch="deep2")
+        g0, _ = _grads_in_fresh_process(tmp_path, "deep_off_%d" % n, n, {"UNET_NO_DEEP_KERNELS": "1"}, arch="deep2")
+        gf, _ = _grads_in_fresh_process(tmp_path, "fp32_%d" % n, n, {}, arch="deep2", dtype="fp32")
+        assert np.abs(g1 - g0).max() > 0, "the switch did not reach the engine"
+        a1, a0, af = _by_name(g1, names), _by_name(g0, names), _by_name(gf, names)
+        floor = 1e-2 * np.abs(gf).max()
+        for nm in af:
+            e1, e0, ref = np.abs(a1[nm] - af[nm]).max(), np.abs(a0[nm] - af[nm]).max(), max(np.abs(af[nm]).max(), floor)
+            assert e1 <= 2.0 * e0 + 5e-3 * ref, (n, nm, e1 / ref, e0 / ref)
+            assert e1 <= 0.6 * ref, (n, nm, e1 / ref)      # (a wrong tap or channel is off by O(1) on most elements; bf16 with 64-voxel norms: the old path measures 0.17-0.35 on single elements of encode1.3.weight at 8^3)
+    d1, _ = _grads_in_fresh_process(tmp_path, "deep_default", 32, {}, arch="default")
+    d1b, _ = _grads_in_fresh_process(tmp_path, "deep_default_again", 32, {}, arch="default")
+    d0, _ = _grads_in_fresh_process(tmp_path, "deep_default_off", 32, {"UNET_NO_DEEP_KERNELS": "1"}, arch="default")
+    assert np.array_equal(d1, d1b) and np.abs(d1 - d0).max() > 0
+    # (the six-level network amplifies the summation-order noise of its 1^3 .. 4^3 levels: only the sizes are comparable there)
+    assert abs(np.linalg.norm(d1) - np.linalg.norm(d0)) <= 5e-2 * np.linalg.norm(d0)
 
 
 def test_halo_tile_kernels_still_match_the_oracle():

@@ -3,7 +3,7 @@
 # Objects are compiled in parallel (one hipcc per source) and only when the source or a header is newer.
 set -e
 cd "$(dirname "$0")"
-SRCS="graph.cpp engine.cpp comm.cpp kernels_direct.hip kernels_elem.hip kernels_mfma_conv.hip kernels_mfma_conv_z16.hip kernels_mfma_s2.hip kernels_mfma_s2_wgrad.hip kernels_mfma_wgrad.hip kernels_mfma_wgrad_z.hip kernels_mfma_wgrad_zd.hip kernels_augment.hip kernels_mfma_f32.hip"
+SRCS="graph.cpp engine.cpp comm.cpp kernels_direct.hip kernels_elem.hip kernels_mfma_conv.hip kernels_mfma_deep.hip kernels_mfma_conv_z16.hip kernels_mfma_s2.hip kernels_mfma_s2_wgrad.hip kernels_mfma_wgrad.hip kernels_mfma_wgrad_z.hip kernels_mfma_wgrad_zd.hip kernels_augment.hip kernels_mfma_f32.hip"
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-result"
 mkdir -p build
 newest_hdr=$(ls -t *.h *.hpp ../../include/*.h | head -1)

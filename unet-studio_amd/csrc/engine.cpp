@@ -85,6 +85,8 @@ struct unet_plan {
     // unet_backward_part call on the same workspace (the bucketed backward must make the same choices as the whole one): workspace -> {tensor, rows}
     mutable std::mutex bn_mu;
     mutable std::unordered_map<const void*, std::pair<int, int>> bn_pending;
+    // ... and the tensors whose whole norm backward a deep-level dgrad already ran in its epilogue (kernels_mfma_deep.hip): workspace -> tensors
+    mutable std::unordered_map<const void*, std::vector<int>> bn_done;
     std::vector<char> use_mfma;              // per op: forward runs on the MFMA kernel
     std::vector<char> dgrad_mfma;            // per op: dgrad runs on the MFMA kernel
     std::vector<char> wgrad_mfma;            // per op: wgrad runs on the MFMA kernel
@@ -120,6 +122,9 @@ struct unet_plan {
     int pack_split_op = 0;
     int64_t pack_split_blocks = 0, pack_fwd_blocks = 0;
     size_t head_off = 0;                     // scratch of the fused head backward (stays on the main stream)
+    // the deep levels' split-K kernels (kernels_mfma_deep.hip): fp32 partial tiles + arrival counters, used on the caller's stream only
+    size_t deep_part_off = 0, deep_part_bytes = 0, deep_cnt_off = 0;
+    static constexpr int deep_ncnt = 4096;
     std::vector<size_t> head_op_off;         // per op: a head's own slab region (its reduce runs on the side stream, later) or SIZE_MAX
 
     ~unet_plan() {
@@ -323,6 +328,11 @@ struct unet_plan {
         }
         wgrad_off = take(wmax ? wmax : 256);
         head_off = take(hmax ? hmax : 256);
+        if (dtype == UNET_DTYPE_BF16 && impl == UNET_IMPL_AUTO) {
+            deep_part_bytes = (size_t)8 << 20;
+            deep_part_off = take(deep_part_bytes);
+            deep_cnt_off = take((size_t)deep_ncnt * 4);
+        }
         head_op_off.assign(g.ops.size(), SIZE_MAX);
         for (size_t i = 0; i < g.ops.size(); ++i) {
             const Op& op = g.ops[i];
@@ -406,7 +416,16 @@ struct Exec {
     const unet_plan& p;
     char* ws;
     hipStream_t s;
+    // the deep levels' kernels may run in this call: the workspace's arrival counters are known to be zero (cleared by the batched filter
+    // pack of this forward, or of the forward whose packs / activations this call works on)
+    bool deep_on = false;
     Exec(const unet_plan& plan, void* workspace, void* stream) : p(plan), ws((char*)workspace), s((hipStream_t)stream) {}
+    DeepScratch deep() const {
+        DeepScratch d;
+        if (deep_on && p.deep_part_bytes) { d.part = (float*)(ws + p.deep_part_off); d.part_bytes = p.deep_part_bytes; d.cnt = (int*)(ws + p.deep_cnt_off); d.ncnt = p.deep_ncnt; }
+        return d;
+    }
+    int* deep_cnt() const { return p.deep_part_bytes ? (int*)(ws + p.deep_cnt_off) : nullptr; }
 
     void* tptr(int t) const { return ws + p.t_off[t]; }
     void* gptr(int t) const { return p.g_off[t] == SIZE_MAX ? nullptr : ws + p.g_off[t]; }
@@ -452,9 +471,10 @@ struct Exec {
         mode &= 1;
         std::vector<int> fused_blocks(g.norms.size(), 0);   // > 0: the producing conv already wrote the statistics partials
         std::vector<char> fused_dbl(g.norms.size(), 0);     // ... as fp64 rows (the fp32 engine)
+        std::vector<char> fused_done(g.norms.size(), 0);    // the producing conv ran the whole norm layer in its epilogue (kernels_mfma_deep.hip)
         // parameters in one flat contiguous buffer (the hosts allocate them so): every MFMA filter pack in ONE launch
         bool packed = false, pack_pending = false, pack2_pending = false;
-        if (p.jobs_dev && packs_current) packed = true;
+        if (p.jobs_dev && packs_current) { packed = true; deep_on = true; }
         else if (p.jobs_dev) {
             bool flat = true;
             for (size_t i = 0; i < g.params.size() && flat; ++i) flat = params[i] == params[0] + p.p_off[i];
@@ -473,7 +493,7 @@ struct Exec {
                         // grid for the later launches (no gain), the dgrad packs launched when the caller's stream reaches the 16^3 level
                         // (2.925-2.935 ms against 2.915: their 5800 short blocks delay the small levels' latency-bound kernels by more
                         // than they cost the bandwidth-bound ones), one launch for everything (a 20-us bubble in front of the first MFMA conv).
-                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_split_blocks, p.side);
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_split_blocks, p.side, 0, 0, deep_cnt(), p.deep_ncnt);
                         HIP_OK(hipEventRecord(p.ev_join, p.side));
                         launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_fwd_blocks - p.pack_split_blocks, p.side, p.pack_split_blocks);
                         HIP_OK(hipEventRecord(p.ev_pack, p.side));
@@ -481,16 +501,17 @@ struct Exec {
                         launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks - p.pack_fwd_blocks, p.side, p.pack_fwd_blocks);
                         HIP_OK(hipEventRecord(p.ev_packd, p.side));
                     } else {
-                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks, p.side);
+                        launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, p.pack_blocks, p.side, 0, 0, deep_cnt(), p.deep_ncnt);
                         HIP_OK(hipEventRecord(p.ev_join, p.side));
                     }
                     pack_pending = true;
                 } else {
                     // an inference forward never reads a dgrad pack
                     ProfScope ps(-1, UNET_PROF_OTHER, s);
-                    launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, mode == 1 ? p.pack_blocks : p.pack_fwd_blocks, s);
+                    launch_mfma_pack_batched(params[0], ws, p.jobs_dev, njobs, mode == 1 ? p.pack_blocks : p.pack_fwd_blocks, s, 0, 0, deep_cnt(), p.deep_ncnt);
                 }
                 packed = true;
+                deep_on = true;
             }
         }
         auto need_packs = [&](int op_index = 1 << 30) {
@@ -520,6 +541,21 @@ struct Exec {
                             launch_pack_conv_w(params[op.weight], wf, wd, op.cin, op.cout, op.ks * op.ks * op.ks, s);
                         const Tensor& T = g.tensors[op.dst];
                         bool want_stats = T.norm >= 0 && !(g.norms[T.norm].batch && mode == 0);
+                        // the deep levels: split-K kernel, the norm layer behind the conv in its epilogue (statistics, running statistics,
+                        // activated copy: the OP_NORM that follows has nothing left to do)
+                        if (deep_on && deep_conv_applies(p.dtype, T.voxels(), op.cin, op.cout)) {
+                            DeepNormFwd nf;
+                            const bool fuse = T.norm >= 0 && p.a_off[op.dst] != SIZE_MAX;
+                            if (fuse) {
+                                const Norm& n = g.norms[T.norm];
+                                nf = {params[n.gamma], params[n.beta], n.eps, stat(T.norm), n.batch ? buffers[n.buffer] : nullptr,
+                                      n.batch ? buffers[n.buffer + 1] : nullptr, 0.1, (n.batch && mode == 0) ? 1 : 0, T.act, ws + p.a_off[op.dst]};
+                            }
+                            if (launch_deep_conv_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst), fuse ? &nf : nullptr, deep(), s)) {
+                                if (fuse) fused_done[T.norm] = 1;
+                                break;
+                            }
+                        }
                         int rows = launch_mfma_conv_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst),
                                                         want_stats ? partial() : nullptr, s);
                         if (want_stats) fused_blocks[T.norm] = rows;
@@ -561,7 +597,8 @@ struct Exec {
                                                op.out_level >= 0 ? outs[op.out_level] : nullptr, s);
                     } else if (p.use_mfma[i]) {
                         if (!packed) launch_mfma_pack_convt_w(params[op.weight], ws + p.wm_fwd[i], mode == 1 ? ws + p.wm_dgrad[i] : nullptr, cg, s);
-                        launch_mfma_convt_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst), s);
+                        if (!(deep_on && launch_deep_convt_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst), deep(), s)))
+                            launch_mfma_convt_fwd(cg, sd, op.nsrc, ws + p.wm_fwd[i], params[op.bias], tptr(op.dst), s);
                     } else {
                         if (!packs_current) launch_pack_convt_w(params[op.weight], wf, wd, op.cin, op.cout, s);
                         if (p.impl == UNET_IMPL_AUTO && convt_f32_mfma_supported(p.dtype, cg, sd, op.nsrc))
@@ -574,6 +611,7 @@ struct Exec {
                 case OP_NORM: {
                     const Norm& n = g.norms[op.norm];
                     const Tensor& T = g.tensors[n.tensor];
+                    if (fused_done[op.norm]) break;
                     if (n.batch && mode == 0) {
                         launch_norm_eval(n.C, params[n.gamma], params[n.beta], buffers[n.buffer], buffers[n.buffer + 1], n.eps,
                                          stat(op.norm), s);
@@ -641,6 +679,11 @@ struct Exec {
             int rows = stats_blocks(T.voxels()), have = 0;
             {
                 std::lock_guard<std::mutex> lk(p.bn_mu);
+                auto d = p.bn_done.find(ws);
+                if (d != p.bn_done.end()) {
+                    auto f = std::find(d->second.begin(), d->second.end(), t);
+                    if (f != d->second.end()) { d->second.erase(f); return; }    // dL/d(raw), the affine gradients and coef() are already there
+                }
                 auto it = p.bn_pending.find(ws);
                 if (it != p.bn_pending.end()) { if (it->second.first == t) have = it->second.second; p.bn_pending.erase(it); }
             }
@@ -669,6 +712,11 @@ struct Exec {
         // (A.forward, B.forward, B.backward, A.backward) a consumed-once flag let A's backward run ahead of A's packs.  The event's latest
         // record is behind every earlier pack on the side stream, and waiting on a never-recorded or completed event costs nothing.
         if (p.side) HIP_OK(hipStreamWaitEvent(s, p.ev_packd, 0));
+        {   // the deep levels' kernels: only behind a forward that made its packs with the batched launch (which cleared the counters)
+            bool flat = p.jobs_dev != nullptr;
+            for (size_t k = 0; k < g.params.size() && flat; ++k) flat = params[k] == params[0] + p.p_off[k];
+            deep_on = flat;
+        }
         std::vector<char> init(g.tensors.size(), 0);
         auto dst_of = [&](int t) {
             DstGrad d;
@@ -691,7 +739,7 @@ struct Exec {
             HIP_OK(hipStreamWaitEvent(sb, p.ev_fork, 0));
         };
         if (op_lo < 0) op_lo = 0;
-        if (op_hi >= (int)g.ops.size()) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending.erase(ws); }   // a new backward starts
+        if (op_hi >= (int)g.ops.size()) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending.erase(ws); p.bn_done.erase(ws); }   // a new backward starts
         // gradients in one flat buffer (both hosts allocate them so): the sliding-window wgrads only write their slabs here and ONE
         // batched reduce at the end of this call adds them all into the gradients
         bool gflat = p.wz_jobs_dev != nullptr;
@@ -866,7 +914,17 @@ struct Exec {
                             // gradient: for the skip tensors that is the stride-2 conv, whose dgrad (k_s2_scatter) fetches the old gradient
                             // and the raw tensor by LDS-DMA and has the epilogue too.  (Stride-1 kernels only take it when they WRITE.)
                             const bool can = op.nsrc == 1 && Ts.norm >= 0 && p.first_consumer[ts] == i && p.dtype == UNET_DTYPE_BF16;
-                            const int rows = launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s, can ? &bn : nullptr);
+                            int rows = 0, served = 0;
+                            if (deep_on) {      // the deep levels: split-K kernel; as the last writer of a norm layer's view it runs that norm's backward too
+                                DeepNormBwd nb;
+                                if (can) {
+                                    const Norm& n = g.norms[Ts.norm];
+                                    nb = {tptr(ts), stat(Ts.norm), params[n.gamma], coef(Ts.norm), gparams[n.gamma], gparams[n.beta], Ts.act};
+                                }
+                                served = launch_deep_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, can ? &nb : nullptr, deep(), s);
+                                if (served == 2) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_done[ws].push_back(ts); }
+                            }
+                            if (!served) rows = launch_mfma_conv_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s, can ? &bn : nullptr);
                             if (rows > 0) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_pending[ws] = {ts, rows}; }
                         }
                         else if (!dry && any && p.impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(p.dtype, cg, dg, op.nsrc))
@@ -874,7 +932,21 @@ struct Exec {
                         else if (!dry && (any)) launch_conv_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     } else {
                         ProfScope pd(i, UNET_PROF_DGRAD, s);
-                        if (!dry && (any && p.dgrad_mfma[i])) launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        if (!dry && (any && p.dgrad_mfma[i])) {
+                            const int ts = op.src[0];
+                            const Tensor& Ts = g.tensors[ts];
+                            const bool can = op.nsrc == 1 && Ts.norm >= 0 && p.first_consumer[ts] == i && p.dtype == UNET_DTYPE_BF16;
+                            DeepNormBwd nb;
+                            if (can) {
+                                const Norm& n = g.norms[Ts.norm];
+                                nb = {tptr(ts), stat(Ts.norm), params[n.gamma], coef(Ts.norm), gparams[n.gamma], gparams[n.beta], Ts.act};
+                            }
+                            int norm_done = 0;
+                            if (deep_on && launch_deep_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, can ? &nb : nullptr, deep(), &norm_done, s)) {
+                                if (norm_done) { std::lock_guard<std::mutex> lk(p.bn_mu); p.bn_done[ws].push_back(ts); }
+                            } else
+                                launch_mfma_convt_dgrad(cg, gptr(t), ws + p.wm_dgrad[i], dg, op.nsrc, s);
+                        }
                         else if (!dry && (any)) launch_convt_dgrad_direct(p.dtype, cg, gptr(t), wd, dg, op.nsrc, s);
                     }
                     if (any) mark(op);
@@ -1395,7 +1467,7 @@ int unet_pack_filters(const unet_plan* p, const float* const* params, void* work
             if (params[i] != params[0] + p->p_off[i]) return 0;
         DeviceGuard dg(p->device);
         launch_mfma_pack_batched(params[0], workspace, p->jobs_dev, (int)p->pack_jobs.size(), with_dgrad ? p->pack_blocks : p->pack_fwd_blocks,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, 0, 0, p->deep_part_bytes ? (int*)((char*)workspace + p->deep_cnt_off) : nullptr, p->deep_ncnt);
         check_launch();
         *made = 1;
         return 0;
@@ -1488,6 +1560,26 @@ static void op_pack(const float* w, int cin, int cout, int k3, bool transposed, 
     else launch_pack_conv_w(w, *wf, *wd, cin, cout, k3, s);
 }
 #define OP_TRY(...) try { __VA_ARGS__; check_launch(); return 0; } catch (const std::exception& e) { return fail(e.what()); }
+// the single-op surface runs the deep levels' kernels (kernels_mfma_deep.hip) as the engine does; their partial tiles and arrival counters
+// live in one allocation per device, made (and cleared) on first use -- every launch leaves the counters zero.  Ops of this surface
+// that use it must not run concurrently on two streams of one device (the tests and tools that call it are single-stream).
+static DeepScratch op_deep() {
+    static std::mutex mu;
+    static std::unordered_map<int, DeepScratch> per_dev;
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_dev.find(dev);
+    if (it != per_dev.end()) return it->second;
+    DeepScratch d;
+    d.part_bytes = (size_t)8 << 20; d.ncnt = 4096;
+    char* base = nullptr;
+    HIP_OK(hipMalloc((void**)&base, d.part_bytes + (size_t)d.ncnt * 4));
+    HIP_OK(hipMemset(base + d.part_bytes, 0, (size_t)d.ncnt * 4));
+    d.part = (float*)base; d.cnt = (int*)(base + d.part_bytes);
+    per_dev[dev] = d;
+    return d;
+}
 
 int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const float* b, void* y, int cin, int cout, int D, int H,
                        int W, int ks, int stride, void* scratch, void* stream) {
@@ -1499,7 +1591,7 @@ int unet_op_conv3d_fwd(int dtype, int impl, const void* x, const float* w, const
         if (impl == UNET_IMPL_AUTO && mfma_conv_fwd_supported(dtype, g, &sd, 1)) {
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_conv_w(w, wm, nullptr, g, s);
-            launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, nullptr, s);
+            if (!launch_deep_conv_fwd(g, &sd, 1, wm, b, y, nullptr, op_deep(), s)) launch_mfma_conv_fwd(g, &sd, 1, wm, b, y, nullptr, s);
         } else if (impl == UNET_IMPL_AUTO && conv_first_mfma_supported(dtype, g, &sd, 1)) {
             launch_conv_first_mfma(g, &sd, w, b, y, nullptr, s);
         } else if (impl == UNET_IMPL_AUTO && conv_first_f32_mfma_supported(dtype, g, &sd, 1)) {
@@ -1576,7 +1668,7 @@ int unet_op_conv3d_bwd_data(int dtype, int impl, const void* dy, const float* w,
         if (impl == UNET_IMPL_AUTO && mfma_conv_dgrad_supported(dtype, g, &sd, 1)) {
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_conv_w(w, nullptr, wm, g, s);
-            launch_mfma_conv_dgrad(g, dy, wm, &d, 1, s);
+            if (!launch_deep_conv_dgrad(g, dy, wm, &d, 1, nullptr, op_deep(), s)) launch_mfma_conv_dgrad(g, dy, wm, &d, 1, s);
         } else {
             op_pack(w, cin, cout, ks * ks * ks, false, scratch, &wf, &wd, s);
             if (impl == UNET_IMPL_AUTO && conv_f32_mfma_dgrad_supported(dtype, g, &d, 1)) launch_conv_f32_mfma_dgrad(g, (const float*)dy, wd, &d, 1, s);
@@ -1614,7 +1706,7 @@ int unet_op_convt_fwd(int dtype, int impl, const void* x, const float* w, const 
         if (impl == UNET_IMPL_AUTO && mfma_convt_supported(dtype, g, &sd, 1)) {
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_convt_w(w, wm, nullptr, g, s);
-            launch_mfma_convt_fwd(g, &sd, 1, wm, b, y, s);
+            if (!launch_deep_convt_fwd(g, &sd, 1, wm, b, y, op_deep(), s)) launch_mfma_convt_fwd(g, &sd, 1, wm, b, y, s);
         } else {
             op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
             if (impl == UNET_IMPL_AUTO && convt_f32_mfma_supported(dtype, g, &sd, 1)) launch_convt_f32_mfma(g, &sd, wf, b, (float*)y, s);
@@ -1633,7 +1725,7 @@ int unet_op_convt_bwd_data(int dtype, int impl, const void* dy, const float* w, 
         if (impl == UNET_IMPL_AUTO && mfma_convt_supported(dtype, g, &sd, 1)) {
             void* wm = (char*)scratch + 2 * align_up((size_t)27 * round_up(cin, 8) * round_up(cout, 8) * 4);
             launch_mfma_pack_convt_w(w, nullptr, wm, g, s);
-            launch_mfma_convt_dgrad(g, dy, wm, &d, 1, s);
+            if (!launch_deep_convt_dgrad(g, dy, wm, &d, 1, nullptr, op_deep(), nullptr, s)) launch_mfma_convt_dgrad(g, dy, wm, &d, 1, s);
         } else {
             op_pack(w, cin, cout, 8, true, scratch, &wf, &wd, s);
             launch_convt_dgrad_direct(dtype, g, dy, wd, &d, 1, s);

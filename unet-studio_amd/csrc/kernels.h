@@ -141,9 +141,9 @@ struct PackJob { int64_t src_off, dst_off, total, blk0; int Ci, Co, CK, T, mode,
 int mfma_conv_pack_jobs(const ConvGeom& g, bool want_dgrad, PackJob* out2);
 int mfma_convt_pack_jobs(const ConvGeom& g, PackJob* out2);
 // one launch serves the pack units [blk_base, blk_base + nblocks) of the table (njobs = the whole table); max_grid > 0 bounds the
-// number of blocks (a block then walks several units)
+// number of blocks (a block then walks several units); zero / nzero: ints the launch also clears (the deep levels' arrival counters)
 void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s,
-                              int64_t blk_base = 0, int max_grid = 0);
+                              int64_t blk_base = 0, int max_grid = 0, int* zero = nullptr, int nzero = 0);
 bool mfma_conv_fwd_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_conv_w_bytes(const ConvGeom& g);
 void launch_mfma_pack_conv_w(const float* w, void* w_mfma_fwd, void* w_mfma_dgrad, const ConvGeom& g, hipStream_t s);
@@ -247,6 +247,29 @@ bool launch_s2_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma
 int s2_wgrad_splits(int Ca, int Cb, int cD, int cH, int cW);
 int launch_s2_wgrad(int ks, const void* fine, const void* fine2, int C0, int Ca, int fD, int fH, int fW, const void* coarse, int Cb, int cD, int cH,
                     int cW, bool want_bias, int bias_from_a, void* scratch, hipStream_t s, int polite);
+// kernels_mfma_deep.hip: the deep levels (output grids of DEEP_MAX_VOXELS voxels or fewer): split-K implicit GEMM straight from global
+// memory, finished by the block that arrives last; with nf / nb the norm layer behind (forward) or in front of (backward) the conv runs
+// in that epilogue too.  The launchers below are tried first by the engine; false / 0 = shape not served.  DeepScratch: fp32 partial tiles
+// and the arrival counters (ints, ZERO before the first launch; every launch leaves them zero) of one workspace.
+constexpr int64_t DEEP_MAX_VOXELS = 512;
+struct DeepScratch { float* part = nullptr; size_t part_bytes = 0; int* cnt = nullptr; int ncnt = 0; };
+struct DeepNormFwd {      // the norm + activation on the conv's output: statistics of this launch (use_running == 0) or the running ones
+    const float* gamma; const float* beta; double eps; float* stat; float* rm; float* rv; double momentum; int use_running; int act;
+    void* act_out;        // the activated copy [voxel][Cout] bf16
+};
+struct DeepNormBwd {      // the norm + activation whose view the dgrad's destination is: u = the raw tensor, stat = {mean, rstd, scale, shift}
+    const void* u; const float* stat; const float* gamma; float* coef; float* dgamma; float* dbeta; int act;
+};
+bool deep_conv_applies(int dtype, int64_t out_voxels, int cin, int cout);
+bool launch_deep_conv_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
+                          const DeepNormFwd* nf, const DeepScratch& sc, hipStream_t s);
+bool launch_deep_convt_fwd(const ConvGeom& g, const SrcDesc* src, int nsrc, const void* w_mfma, const float* bias, void* out,
+                           const DeepScratch& sc, hipStream_t s);
+// 0: not served; 1: gradient written / accumulated; 2: ... and the destination's norm backward done in place (nb given, one destination)
+int launch_deep_conv_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, const DeepNormBwd* nb,
+                           const DeepScratch& sc, hipStream_t s);
+bool launch_deep_convt_dgrad(const ConvGeom& g, const void* dy, const void* w_mfma_dgrad, const DstGrad* dst, int ndst, const DeepNormBwd* nb,
+                             const DeepScratch& sc, int* norm_done, hipStream_t s);
 // ConvTranspose3d 2x2x2 stride 2: forward (1x1 GEMM + depth-to-space scatter) and dgrad (2x2x2 stride-2 conv of dL/dy)
 bool mfma_convt_supported(int dtype, const ConvGeom& g, const SrcDesc* src, int nsrc);
 size_t mfma_convt_w_bytes(const ConvGeom& g);

@@ -126,8 +126,13 @@ __global__ void __launch_bounds__(256) k_mfma_pack(const float* __restrict__ w, 
 // blockIdx.x + gridDim.x, ... (the deep levels' packs run on the side stream beside the forward's first convs and are not needed
 // before the caller's stream reaches those levels: a bounded grid leaves the CUs' LDS and wave slots to the convs).
 __global__ void __launch_bounds__(256) k_mfma_pack_batched(const float* __restrict__ params_base, char* __restrict__ ws,
-                                                           const PackJob* __restrict__ jobs, int njobs, int64_t blk_base, int64_t nunits) {
+                                                           const PackJob* __restrict__ jobs, int njobs, int64_t blk_base, int64_t nunits,
+                                                           int* __restrict__ zero, int nzero) {
     __shared__ __bf16 lds[PACK_LDS_ELEMS];
+    // the first pack launch of a forward also clears the deep levels' arrival counters (kernels_mfma_deep.hip): every consumer of a
+    // counter waits for this launch anyway (it reads a filter pack), so the workspace needs no separate initialisation
+    if (zero && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
     for (int64_t u = blockIdx.x; u < nunits; u += gridDim.x) {
         const int64_t blk = blk_base + u;
         int lo = 0, hi = njobs - 1;
@@ -142,10 +147,10 @@ __global__ void __launch_bounds__(256) k_mfma_pack_batched(const float* __restri
     }
 }
 void launch_mfma_pack_batched(const float* params_base, void* ws, const PackJob* jobs_dev, int njobs, int64_t nblocks, hipStream_t s,
-                              int64_t blk_base, int max_grid) {
+                              int64_t blk_base, int max_grid, int* zero, int nzero) {
     if (njobs <= 0 || nblocks <= 0) return;
     const int64_t grid = (max_grid > 0 && nblocks > max_grid) ? max_grid : nblocks;
-    k_mfma_pack_batched<<<(unsigned)grid, 256, 0, s>>>(params_base, (char*)ws, jobs_dev, njobs, blk_base, nblocks);
+    k_mfma_pack_batched<<<(unsigned)grid, 256, 0, s>>>(params_base, (char*)ws, jobs_dev, njobs, blk_base, nblocks, zero, nzero);
 }
 
 static inline int pick_ck(int Ci, bool allow32) { return (allow32 && Ci % 32 == 0) ? 32 : 16; }
