@@ -79,7 +79,9 @@ __device__ __forceinline__ void deep_publish(float* p, f32x4 v) {
     __hip_atomic_store((unsigned long long*)p, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store((unsigned long long*)p + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+template <bool COH>     // COH: the partials were written by other blocks of THIS launch (ticket path); else by an earlier launch
 __device__ __forceinline__ f32x4 deep_fetch(const float* p) {
+    if (!COH) return *(const f32x4*)p;
     const unsigned long long lo = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long hi = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
@@ -87,7 +89,7 @@ __device__ __forceinline__ f32x4 deep_fetch(const float* p) {
 
 // the K ranges of a thread's rows (row it = voxel it * 64 + tid / 4, it < iters <= IT), summed in K-range order; 16 partial rows in
 // flight per round whatever the volume: IT rows x 16 / IT K ranges
-template <int IT>
+template <int IT, bool COH>
 __device__ __forceinline__ void deep_sum_parts(const float* pp, size_t kstride, int ksplit, int iters, f32x4 (&sum)[8]) {
     constexpr int KU = 16 / IT;
     for (int ks0 = 0; ks0 < ksplit; ks0 += KU) {
@@ -96,7 +98,7 @@ __device__ __forceinline__ void deep_sum_parts(const float* pp, size_t kstride, 
         for (int it = 0; it < IT; ++it)
 #pragma unroll
             for (int u = 0; u < KU; ++u)
-                t[it][u] = (it < iters && ks0 + u < ksplit) ? deep_fetch(pp + (size_t)(ks0 + u) * kstride + (size_t)it * 64 * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+                t[it][u] = (it < iters && ks0 + u < ksplit) ? deep_fetch<COH>(pp + (size_t)(ks0 + u) * kstride + (size_t)it * 64 * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < IT; ++it)
 #pragma unroll
@@ -123,126 +125,13 @@ __device__ __forceinline__ void deep_reduce16(const float (&sa)[4], const float 
     __syncthreads();
 }
 
-template <int S, int KD, int PAD, bool SC, int EPI, int NTW>
-__global__ void __launch_bounds__(256) k_deep_conv(DeepArgs a) {
-    constexpr int T = KD * KD * KD, PF = 4;
-    static_assert(EPI == DEEP_PLAIN || !SC, "a norm epilogue owns whole channels: no scatter kinds");
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * NTW * 64 * 4];
-    __shared__ double dsum[32 + 128];
-    __shared__ float s_par[64];
-    __shared__ int s_last;
+// The finish of an output tile set by the last arriver: sums the K ranges' partial tiles in K-range order and runs the epilogue (COH:
+// the loads come from the memory side).  Loads are requested in batches before the first use (a loop of load -> wait -> add per K range and per row made the 512-voxel levels
+// 31-44 us per launch: profiles/r20a_step_launch_sequence.txt).
+template <bool SC, int EPI, int NTW, bool COH>
+__device__ __forceinline__ void deep_finish(const DeepArgs& a, int mg, int ng, double* dsum, float* s_par) {
     const ConvGeom& g = a.c.g;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
-    const int NTT = g.Cout / 16, NG = NTT / NTW, NGK = NG * a.ksplit;
-    // blocks that read the same filter slice (same row tiles and K range, different voxel group) are NGK apart: the same XCD (NGK % 8 == 0
-    // whenever MG > 1 matters: the launcher keeps NG * ksplit a multiple of 8 there), one HBM read of the slice per XCD at most
-    const int ngk = blockIdx.x % NGK, mg = blockIdx.x / NGK, ng = ngk % NG, ksp = ngk / NG;
-    const int KS = T * a.nchunk;
-    const int k0 = ksp * a.kper, k1 = k0 + a.kper < KS ? k0 + a.kper : KS;
-    const int per = (k1 - k0 + 3) >> 2;
-    const int kw0 = k0 + wave * per, kw1 = kw0 + per < k1 ? kw0 + per : k1;
-
-    int oz[4], oy[4], ox[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = mg * 64 + i * 16 + j;
-        ox[i] = m % g.Wo;
-        const int r = m / g.Wo;
-        oy[i] = r % g.Ho;
-        oz[i] = m < a.V ? r / g.Ho : -(1 << 20);       // a row past the grid reads zeros (every tap lands outside the volume)
-    }
-    const bf16x8* wp = (const bf16x8*)a.c.w + (size_t)(ng * NTW) * 64 + lane;
-    const int C0 = a.c.src[0].C;
-    f32x4 acc[4][NTW];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xb[PF][4], wb[PF][NTW];
-    // The K loop: PF k-steps of operands in flight in registers.  Every load is UNCONDITIONAL (a voxel outside the volume reads the
-    // zero page, a k-step past the wave's range repeats the last one): with a branch around a load the compiler can no longer count the
-    // loads in flight and waits for all of them (vmcnt(0)) before the first MFMA of every round -- one exposed memory latency per PF
-    // k-steps (measured: 1.4 us per k-step at the 8^3 levels).  Straight-line rounds get counted waits (vmcnt((PF - 1) * (4 + NTW))).
-    const int nst = kw1 > kw0 ? kw1 - kw0 : 0;
-    int pt = nst ? kw0 / a.nchunk : 0, pq = nst ? kw0 - pt * a.nchunk : 0, rem = nst;   // the next k-step to request: (tap, chunk)
-
-#define DEEP_ISSUE(st)                                                                                                              \
-    {                                                                                                                               \
-        const int kz = pt / (KD * KD), ky = (pt / KD) % KD, kx = pt % KD, cch = pq * 32;                                            \
-        const bool second = a.c.nsrc > 1 && cch >= C0;                                                                              \
-        const char* sbase = (const char*)(second ? a.c.src[1].ptr : a.c.src[0].ptr);                                               \
-        const int sC = second ? a.c.src[1].C : C0, cc = (second ? cch - C0 : cch) + gq * 8;                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                            \
-            const int iz = S * oz[i] + kz - PAD, iy = S * oy[i] + ky - PAD, ix = S * ox[i] + kx - PAD;                              \
-            const bool ok = (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;           \
-            const char* xp = ok ? sbase + ((size_t)((iz * g.H + iy) * g.W + ix) * sC + cc) * 2 : (const char*)g_deep_zero;         \
-            xb[st][i] = *(const bf16x8*)xp;                                                                                         \
-        }                                                                                                                           \
-        _Pragma("unroll") for (int n = 0; n < NTW; ++n) wb[st][n] = wp[((size_t)(pq * T + pt) * NTT + n) * 64];                    \
-        if (rem > 1) { --rem; if (++pq == a.nchunk) { pq = 0; ++pt; } }                                                             \
-    }
-#define DEEP_MFMA(st)                                                                                                               \
-    _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                              \
-            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[st][n], xb[st][i], acc[i][n], 0, 0, 0);
-
-#pragma unroll
-    for (int st = 0; st < PF; ++st) DEEP_ISSUE(st)
-    int kk = 0;
-#pragma unroll 1
-    for (; kk + PF < nst; kk += PF) {        // full rounds: every stage is a k-step of the range and is refilled
-#pragma unroll
-        for (int st = 0; st < PF; ++st) {
-            DEEP_MFMA(st)
-            DEEP_ISSUE(st)
-        }
-    }
-#pragma unroll
-    for (int st = 0; st < PF; ++st)           // the last round (1..PF k-steps): nothing left to request
-        if (kk + st < nst) { DEEP_MFMA(st) }
-#undef DEEP_MFMA
-#undef DEEP_ISSUE
-
-    // ---- the four waves' K quarters; wave w finishes m-tile w ----
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) *(f32x4*)(red + (((wave * 4 + i) * NTW + n) * 64 + lane) * 4) = acc[i][n];
-    __syncthreads();
-    f32x4 o[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        o[n] = *(const f32x4*)(red + (((0 * 4 + wave) * NTW + n) * 64 + lane) * 4);
-#pragma unroll
-        for (int v = 1; v < 4; ++v) {
-            const f32x4 t = *(const f32x4*)(red + (((v * 4 + wave) * NTW + n) * 64 + lane) * 4);
-            o[n][0] += t[0]; o[n][1] += t[1]; o[n][2] += t[2]; o[n][3] += t[3];
-        }
-    }
-    const int mw = mg * 64 + wave * 16 + j;
-    if (EPI == DEEP_PLAIN && a.ksplit == 1) {
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) deep_store<SC>(a, mw, (ng * NTW + n) * 16 + gq * 4, o[n]);
-        return;
-    }
-    // ---- publish the partial tile, take a ticket ----
-#pragma unroll
-    for (int n = 0; n < NTW; ++n)
-        deep_publish(a.part + (((size_t)(ksp * NTT + ng * NTW + n) * a.Vpad + mw) * 16 + gq * 4), o[n]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have completed (no cache maintenance at this scope)
-    __syncthreads();
-    if (tid == 0) {
-        const int cidx = EPI == DEEP_PLAIN ? mg * NG + ng : ng, target = EPI == DEEP_PLAIN ? a.ksplit : a.MG * a.ksplit;
-        const int old = __hip_atomic_fetch_add(a.cnt + cidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = old == target - 1;
-        if (s_last) __hip_atomic_store(a.cnt + cidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-
-    // The last arriver's loads come from the memory side (sc1), ~1 us each under load: everything a thread needs is requested in batches
-    // (DEEP_MAXIT voxel rows x 2 K ranges = 32 loads in flight) before the first use -- a loop of load -> wait -> add per K range and
-    // per row made the 512-voxel levels 31-44 us per launch (profiles/r20a_step_launch_sequence.txt).
+    const int tid = threadIdx.x, NTT = g.Cout / 16;
     const int ml = tid >> 2, rq = tid & 3;
     if (EPI == DEEP_PLAIN) {
         const int m = mg * 64 + ml;
@@ -255,7 +144,7 @@ __global__ void __launch_bounds__(256) k_deep_conv(DeepArgs a) {
             for (int ks0 = 0; ks0 < a.ksplit; ks0 += 8) {
                 f32x4 t[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = ks0 + u < a.ksplit ? deep_fetch(pp + (size_t)(ks0 + u) * kstride) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 8; ++u) t[u] = ks0 + u < a.ksplit ? deep_fetch<COH>(pp + (size_t)(ks0 + u) * kstride) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { sum[0] += t[u][0]; sum[1] += t[u][1]; sum[2] += t[u][2]; sum[3] += t[u][3]; }
             }
@@ -277,10 +166,10 @@ __global__ void __launch_bounds__(256) k_deep_conv(DeepArgs a) {
         {
             const float* pp = a.part + (((size_t)nt * a.Vpad + ml) * 16 + rq * 4);
             const size_t kstride = (size_t)NTT * a.Vpad * 16;
-            if (iters <= 1) deep_sum_parts<1>(pp, kstride, a.ksplit, iters, sum);
-            else if (iters <= 2) deep_sum_parts<2>(pp, kstride, a.ksplit, iters, sum);
-            else if (iters <= 4) deep_sum_parts<4>(pp, kstride, a.ksplit, iters, sum);
-            else deep_sum_parts<8>(pp, kstride, a.ksplit, iters, sum);
+            if (iters <= 1) deep_sum_parts<1, COH>(pp, kstride, a.ksplit, iters, sum);
+            else if (iters <= 2) deep_sum_parts<2, COH>(pp, kstride, a.ksplit, iters, sum);
+            else if (iters <= 4) deep_sum_parts<4, COH>(pp, kstride, a.ksplit, iters, sum);
+            else deep_sum_parts<8, COH>(pp, kstride, a.ksplit, iters, sum);
         }
         if (EPI == DEEP_FWD_NORM) {
             char* y = (char*)a.c.out[0];
@@ -420,6 +309,126 @@ __global__ void __launch_bounds__(256) k_deep_conv(DeepArgs a) {
 }
 
 
+
+template <int S, int KD, int PAD, bool SC, int EPI, int NTW>
+__global__ void __launch_bounds__(256) k_deep_conv(DeepArgs a) {
+    constexpr int T = KD * KD * KD, PF = 4;
+    static_assert(EPI == DEEP_PLAIN || !SC, "a norm epilogue owns whole channels: no scatter kinds");
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * NTW * 64 * 4];
+    __shared__ double dsum[32 + 128];
+    __shared__ float s_par[64];
+    __shared__ int s_last;
+    const ConvGeom& g = a.c.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
+    const int NTT = g.Cout / 16, NG = NTT / NTW, NGK = NG * a.ksplit;
+    // blocks that read the same filter slice (same row tiles and K range, different voxel group) are NGK apart: the same XCD (NGK % 8 == 0
+    // whenever MG > 1 matters: the launcher keeps NG * ksplit a multiple of 8 there), one HBM read of the slice per XCD at most
+    const int ngk = blockIdx.x % NGK, mg = blockIdx.x / NGK, ng = ngk % NG, ksp = ngk / NG;
+    const int KS = T * a.nchunk;
+    const int k0 = ksp * a.kper, k1 = k0 + a.kper < KS ? k0 + a.kper : KS;
+    const int per = (k1 - k0 + 3) >> 2;
+    const int kw0 = k0 + wave * per, kw1 = kw0 + per < k1 ? kw0 + per : k1;
+
+    int oz[4], oy[4], ox[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mg * 64 + i * 16 + j;
+        ox[i] = m % g.Wo;
+        const int r = m / g.Wo;
+        oy[i] = r % g.Ho;
+        oz[i] = m < a.V ? r / g.Ho : -(1 << 20);       // a row past the grid reads zeros (every tap lands outside the volume)
+    }
+    const bf16x8* wp = (const bf16x8*)a.c.w + (size_t)(ng * NTW) * 64 + lane;
+    const int C0 = a.c.src[0].C;
+    f32x4 acc[4][NTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xb[PF][4], wb[PF][NTW];
+    // The K loop: PF k-steps of operands in flight in registers.  Every load is UNCONDITIONAL (a voxel outside the volume reads the
+    // zero page, a k-step past the wave's range repeats the last one): with a branch around a load the compiler can no longer count the
+    // loads in flight and waits for all of them (vmcnt(0)) before the first MFMA of every round -- one exposed memory latency per PF
+    // k-steps (measured: 1.4 us per k-step at the 8^3 levels).  Straight-line rounds get counted waits (vmcnt((PF - 1) * (4 + NTW))).
+    const int nst = kw1 > kw0 ? kw1 - kw0 : 0;
+    int pt = nst ? kw0 / a.nchunk : 0, pq = nst ? kw0 - pt * a.nchunk : 0, rem = nst;   // the next k-step to request: (tap, chunk)
+
+#define DEEP_ISSUE(st)                                                                                                              \
+    {                                                                                                                               \
+        const int kz = pt / (KD * KD), ky = (pt / KD) % KD, kx = pt % KD, cch = pq * 32;                                            \
+        const bool second = a.c.nsrc > 1 && cch >= C0;                                                                              \
+        const char* sbase = (const char*)(second ? a.c.src[1].ptr : a.c.src[0].ptr);                                               \
+        const int sC = second ? a.c.src[1].C : C0, cc = (second ? cch - C0 : cch) + gq * 8;                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                            \
+            const int iz = S * oz[i] + kz - PAD, iy = S * oy[i] + ky - PAD, ix = S * ox[i] + kx - PAD;                              \
+            const bool ok = (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;           \
+            const char* xp = ok ? sbase + ((size_t)((iz * g.H + iy) * g.W + ix) * sC + cc) * 2 : (const char*)g_deep_zero;         \
+            xb[st][i] = *(const bf16x8*)xp;                                                                                         \
+        }                                                                                                                           \
+        _Pragma("unroll") for (int n = 0; n < NTW; ++n) wb[st][n] = wp[((size_t)(pq * T + pt) * NTT + n) * 64];                    \
+        if (rem > 1) { --rem; if (++pq == a.nchunk) { pq = 0; ++pt; } }                                                             \
+    }
+#define DEEP_MFMA(st)                                                                                                               \
+    _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                              \
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[st][n], xb[st][i], acc[i][n], 0, 0, 0);
+
+#pragma unroll
+    for (int st = 0; st < PF; ++st) DEEP_ISSUE(st)
+    int kk = 0;
+#pragma unroll 1
+    for (; kk + PF < nst; kk += PF) {        // full rounds: every stage is a k-step of the range and is refilled
+#pragma unroll
+        for (int st = 0; st < PF; ++st) {
+            DEEP_MFMA(st)
+            DEEP_ISSUE(st)
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < PF; ++st)           // the last round (1..PF k-steps): nothing left to request
+        if (kk + st < nst) { DEEP_MFMA(st) }
+#undef DEEP_MFMA
+#undef DEEP_ISSUE
+
+    // ---- the four waves' K quarters; wave w finishes m-tile w ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) *(f32x4*)(red + (((wave * 4 + i) * NTW + n) * 64 + lane) * 4) = acc[i][n];
+    __syncthreads();
+    f32x4 o[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        o[n] = *(const f32x4*)(red + (((0 * 4 + wave) * NTW + n) * 64 + lane) * 4);
+#pragma unroll
+        for (int v = 1; v < 4; ++v) {
+            const f32x4 t = *(const f32x4*)(red + (((v * 4 + wave) * NTW + n) * 64 + lane) * 4);
+            o[n][0] += t[0]; o[n][1] += t[1]; o[n][2] += t[2]; o[n][3] += t[3];
+        }
+    }
+    const int mw = mg * 64 + wave * 16 + j;
+    if (EPI == DEEP_PLAIN && a.ksplit == 1) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) deep_store<SC>(a, mw, (ng * NTW + n) * 16 + gq * 4, o[n]);
+        return;
+    }
+    // ---- publish the partial tile, take a ticket ----
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+        deep_publish(a.part + (((size_t)(ksp * NTT + ng * NTW + n) * a.Vpad + mw) * 16 + gq * 4), o[n]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's stores have completed (no cache maintenance at this scope)
+    __syncthreads();
+    if (tid == 0) {
+        const int cidx = EPI == DEEP_PLAIN ? mg * NG + ng : ng, target = EPI == DEEP_PLAIN ? a.ksplit : a.MG * a.ksplit;
+        const int old = __hip_atomic_fetch_add(a.cnt + cidx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == target - 1;
+        if (s_last) __hip_atomic_store(a.cnt + cidx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    deep_finish<SC, EPI, NTW, true>(a, mg, ng, dsum, s_par);
+}
+
 // ---- launch plumbing ----
 // UNET_NO_DEEP_KERNELS=1 (read once per process): the halo-tile kernels and the separate norm launches at the deep levels too (also
 // implied by UNET_NO_SLIDING_WINDOW); tests/test_gpu_parity.py compares the two paths in the network
@@ -489,7 +498,9 @@ static MfmaConvArgs deep_base() {
 // Measured per layer of the default architecture at 128^3 (profiles/r20c_step_launch_sequence.txt against r18_step_launch_sequence.txt):
 // at 4^3 a 3x3x3 conv + norm takes 11.5 us here against 20-30 us in two launches; at 8^3 it takes 25-41 us against 20-29 -- with
 // 512..1024 blocks the ticket path (stores acknowledged by the memory side, the atomic's round trip, the last arriver's four rounds of
-// loads over 512 voxels, a second wave of blocks) costs more than the split saves.  So the 27-tap kinds come here at 64 voxels or fewer;
+// loads over 512 voxels, a second wave of blocks) costs more than the split saves; and as two launches (partial tiles with plain stores
+// from 1024 lean blocks, then a finish launch of 16 blocks: profiles/r20d_two_launch_8cube_not_kept_launch_sequence.txt) 17 + 10 us.
+// So the 27-tap kinds come here at 64 voxels or fewer;
 // the short contractions (conv_trans forward and dgrad, the stride-2 dgrad: 1 or 8 taps) win up to DEEP_MAX_VOXELS.
 constexpr int64_t DEEP_K3_MAX_VOXELS = 64;
 bool deep_conv_applies(int dtype, int64_t out_voxels, int cin, int cout) {
