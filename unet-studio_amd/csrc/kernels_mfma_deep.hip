@@ -353,20 +353,32 @@ __global__ void __launch_bounds__(256) k_deep_conv(DeepArgs a) {
     const int nst = kw1 > kw0 ? kw1 - kw0 : 0;
     int pt = nst ? kw0 / a.nchunk : 0, pq = nst ? kw0 - pt * a.nchunk : 0, rem = nst;   // the next k-step to request: (tap, chunk)
 
+    // the input voxel of each of the lane's four rows for the tap being requested (-1: outside the volume), recomputed only when the tap
+    // changes -- k-steps are tap-major, a wave's range covers one or two taps.  (With the voxel arithmetic in every k-step the kernel was
+    // VALU-bound: three quarter-rate 32-bit multiplies per row and k-step, ~400 cycles per k-step against 64 of MFMA.)
+    int vox[4] = {-1, -1, -1, -1};
+    bool newtap = true;
 #define DEEP_ISSUE(st)                                                                                                              \
     {                                                                                                                               \
-        const int kz = pt / (KD * KD), ky = (pt / KD) % KD, kx = pt % KD, cch = pq * 32;                                            \
+        if (newtap) {                                                                                                               \
+            const int kz = pt / (KD * KD), ky = (pt / KD) % KD, kx = pt % KD;                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                        \
+                const int iz = S * oz[i] + kz - PAD, iy = S * oy[i] + ky - PAD, ix = S * ox[i] + kx - PAD;                          \
+                const bool ok = (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;       \
+                vox[i] = ok ? (int)__umul24(__umul24(iz, g.H) + iy, g.W) + ix : -1;                                                 \
+            }                                                                                                                       \
+            newtap = false;                                                                                                         \
+        }                                                                                                                           \
+        const int cch = pq * 32;                                                                                                    \
         const bool second = a.c.nsrc > 1 && cch >= C0;                                                                              \
-        const char* sbase = (const char*)(second ? a.c.src[1].ptr : a.c.src[0].ptr);                                               \
-        const int sC = second ? a.c.src[1].C : C0, cc = (second ? cch - C0 : cch) + gq * 8;                                         \
+        const char* sbase = (const char*)(second ? a.c.src[1].ptr : a.c.src[0].ptr) + ((second ? cch - C0 : cch) + gq * 8) * 2;     \
+        const unsigned vstride = (unsigned)(second ? a.c.src[1].C : C0) * 2u;                                                       \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                            \
-            const int iz = S * oz[i] + kz - PAD, iy = S * oy[i] + ky - PAD, ix = S * ox[i] + kx - PAD;                              \
-            const bool ok = (unsigned)iz < (unsigned)g.D && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;           \
-            const char* xp = ok ? sbase + ((size_t)((iz * g.H + iy) * g.W + ix) * sC + cc) * 2 : (const char*)g_deep_zero;         \
+            const char* xp = vox[i] >= 0 ? sbase + __umul24((unsigned)vox[i], vstride) : (const char*)g_deep_zero;                  \
             xb[st][i] = *(const bf16x8*)xp;                                                                                         \
         }                                                                                                                           \
         _Pragma("unroll") for (int n = 0; n < NTW; ++n) wb[st][n] = wp[((size_t)(pq * T + pt) * NTT + n) * 64];                    \
-        if (rem > 1) { --rem; if (++pq == a.nchunk) { pq = 0; ++pt; } }                                                             \
+        if (rem > 1) { --rem; if (++pq == a.nchunk) { pq = 0; ++pt; newtap = true; } }                                              \
     }
 #define DEEP_MFMA(st)                                                                                                               \
     _Pragma("unroll") for (int n = 0; n < NTW; ++n)                                                                                \
