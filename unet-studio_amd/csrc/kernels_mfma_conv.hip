@@ -543,20 +543,28 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 && NT == 1) ? 4 : 2) k_mfma_
 // statistics {sum dv, sum dv * xhat}, dv = dL/d(view) * act'(u * scale + shift), as one row per tile in a.bn_partial -- the separate
 // k_norm_bwd_stats8 launch (5-6 us of the caller's stream per layer at these levels) is not needed.
 constexpr int SMALL_QS = 8;
-template <int BZ, int BY, int BX, int OCC, bool BNS = false>
-__global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
+// NW = 8 (layers of 256+ input channels): one channel chunk per wave per super-stage instead of two -- the tap loop, the longest link of
+// the block's latency chain after the launch itself, is half as long; waves 4..7 only contribute their K partials.
+template <int BZ, int BY, int BX, int OCC, bool BNS = false, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, OCC) k_mfma_conv_small(MfmaConvArgs a) {
+    constexpr int NTHR = NW * 64;
     constexpr int HZ = BZ + 2, HY = BY + 2, HX = BX + 2, HXP = (HX + 3) / 4 * 4;
     constexpr int TXM = BX < 16 ? BX : 16, TYM = 16 / TXM, RG = BY / TYM;
     constexpr int TILE_B = HZ * HY * HXP * 64;
-    constexpr int UNITS = HZ * HY * HX * 4, ITERS = (UNITS + 255) / 256;
+    constexpr int UNITS = HZ * HY * HX * 4, ITERS = (UNITS + NTHR - 1) / NTHR;
     constexpr int QB = OCC == 1 ? 4 : 2;   // chunks per staging burst (registers: QB * ITERS * 4)
     static_assert(BZ * BY * BX == 64, "four m-tiles per tile");
+    static_assert(NW == 4 || (NW == 8 && OCC == 1), "eight waves: the one-block-per-CU form only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4, lg = tid & 3;
-    const int nt0 = blockIdx.y, NTT = g.Cout / 16, nchunk = g.Cin / 32, C0 = a.src[0].C;
-    const int bid = blockIdx.x;
+    // grid = (row tiles, voxel tiles): workgroups go to the 8 XCDs round-robin in linear order, so blocks of one XCD share their ROW TILE
+    // (the 110-440 KB filter slice is fetched into one L2) and differ in the voxel tile.  With the voxel tile in x every XCD held one
+    // tile and streamed the WHOLE filter: 8 x 3.5 MB per launch at 8^3 (profiles/r20_step_hbm_traffic_per_kernel.txt: 295 MB per step in
+    // 11 launches against 29 MB of filters).
+    const int nt0 = blockIdx.x, NTT = g.Cout / 16, nchunk = g.Cin / 32, C0 = a.src[0].C;
+    const int bid = blockIdx.y;
     const int x0 = (bid % a.tiles_x) * BX, y0 = ((bid / a.tiles_x) % a.tiles_y) * BY, z0 = (bid / (a.tiles_x * a.tiles_y)) * BZ;
     const int iz0 = z0 - 1, iy0 = y0 - 1, ix0 = x0 - 1;
     const bf16x8* wp = (const bf16x8*)a.w;
@@ -575,7 +583,7 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
     unsigned uvox[ITERS], uin = 0;            // uin bit it: the unit exists and lies inside the volume
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
-        const int u = tid + it * 256;
+        const int u = tid + it * NTHR;
         const int hv = u >> 2, hz = hv / (HY * HX), hr = hv % (HY * HX), hy = hr / HX, hx = hr % HX;
         ulds[it] = u < UNITS ? ((hz * HY + hy) * HXP + hx) * 64 + ((lg ^ (((hx >> 2) & 1) << 1)) << 4) : -1;
         uvox[it] = (unsigned)((hz * g.H + hy) * g.W + hx);
@@ -628,10 +636,10 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
         }
         __syncthreads();
 #pragma unroll 1
-        for (int qq = wave; qq < nq; qq += 4) {
+        for (int qq = wave; qq < nq; qq += NW) {
             const char* tile = smem + qq * TILE_B;
-            const bool more = OCC == 1 && qq + 4 < nq;   // OCC 2 is launched with nq <= 4 only: one chunk per wave
-            const bf16x8* wn = wp + ((size_t)(q0 + qq + 4) * 27 * NTT + nt0) * 64 + lane;   // the wave's next chunk (if more)
+            const bool more = OCC == 1 && qq + NW < nq;   // OCC 2 is launched with nq <= 4 only: one chunk per wave
+            const bf16x8* wn = wp + ((size_t)(q0 + qq + NW) * 27 * NTT + nt0) * 64 + lane;   // the wave's next chunk (if more)
             bf16x8 xbuf[2][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) xbuf[0][i] = *(const bf16x8*)(tile + mbase[i][0]);
@@ -651,16 +659,17 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
         }
     }
 
-    // ---- sum the four K-partials; wave w finishes m-tile w ----
+    // ---- sum the NW K-partials; wave w < 4 finishes m-tile w ----
     __syncthreads();
     float* red = (float*)smem;
 #pragma unroll
     for (int i = 0; i < 4; ++i) *(f32x4*)(red + ((wave * 4 + i) * 64 + lane) * 4) = acc[i];
     __syncthreads();
-    f32x4 o4 = *(const f32x4*)(red + ((0 * 4 + wave) * 64 + lane) * 4);
+    const int mt = wave & 3;
+    f32x4 o4 = *(const f32x4*)(red + ((0 * 4 + mt) * 64 + lane) * 4);
 #pragma unroll
-    for (int v = 1; v < 4; ++v) {
-        const f32x4 t = *(const f32x4*)(red + ((v * 4 + wave) * 64 + lane) * 4);
+    for (int v = 1; v < NW; ++v) {
+        const f32x4 t = *(const f32x4*)(red + ((v * 4 + mt) * 64 + lane) * 4);
         o4[0] += t[0]; o4[1] += t[1]; o4[2] += t[2]; o4[3] += t[3];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -675,9 +684,9 @@ __global__ void __launch_bounds__(256, OCC) k_mfma_conv_small(MfmaConvArgs a) {
         const int cd = c - (d ? a.outC[0] : 0);
         char* obase = (char*)(d ? a.out[1] : a.out[0]);
         const int oC = d ? a.outC[1] : a.outC[0], oacc = d ? a.out_acc[1] : a.out_acc[0];
-        const int mz = wave / RG, my = (wave % RG) * TYM + j / TXM, mx = j % TXM;
+        const int mz = mt / RG, my = (mt % RG) * TYM + j / TXM, mx = j % TXM;
         const int gz = z0 + mz, gy = y0 + my, gx = x0 + mx;
-        if (gz < a.oD && gy < a.oH && gx < a.oW && obase) {
+        if (wave < 4 && gz < a.oD && gy < a.oH && gx < a.oW && obase) {
             const size_t vox = ((size_t)gz * a.oH + gy) * a.oW + gx;
             uint2* p = (uint2*)(obase + (vox * oC + cd) * 2);
             float v0 = o4[0] + b4[0], v1 = o4[1] + b4[1], v2 = o4[2] + b4[2], v3 = o4[3] + b4[3];
@@ -1222,7 +1231,18 @@ template <int BZ, int BY, int BX> static int launch_small(const MfmaConvArgs& a0
     set_max_lds_once(attr1_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 1>, (int)(SMALL_QS * tile_b));
     set_max_lds_once(attr2_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 2>, 80 * 1024);
     const int tiles = a.tiles_x * a.tiles_y * a.tiles_z;
-    dim3 grid((unsigned)tiles, (unsigned)(a.g.Cout / 16));
+    dim3 grid((unsigned)(a.g.Cout / 16), (unsigned)tiles);
+    if (nchunk >= 8) {    // 256+ input channels (LDS above 80 KB: one block per CU anyway): eight waves, one chunk each per super-stage
+        static std::atomic<uint64_t> attr5_done{0}, attr6_done{0};
+        if (a.bn_partial) {
+            set_max_lds_once(attr5_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 1, true, 8>, (int)(SMALL_QS * tile_b));
+            k_mfma_conv_small<BZ, BY, BX, 1, true, 8><<<grid, 512, lds, s>>>(a);
+        } else {
+            set_max_lds_once(attr6_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 1, false, 8>, (int)(SMALL_QS * tile_b));
+            k_mfma_conv_small<BZ, BY, BX, 1, false, 8><<<grid, 512, lds, s>>>(a);
+        }
+        return tiles;
+    }
     if (a.bn_partial) {   // dgrad with the norm backward's statistics in the epilogue
         static std::atomic<uint64_t> attr3_done{0}, attr4_done{0};
         set_max_lds_once(attr3_done, (const void*)k_mfma_conv_small<BZ, BY, BX, 1, true>, (int)(SMALL_QS * tile_b));
