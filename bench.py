@@ -336,6 +336,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--step-times", action="store_true", help="diagnostic: event-time every step of the timed region, print the slowest to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-op HIP-event profile (roofline / conv_mfma_frac)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the single-kernel micro-benchmarks (roofline_kernels)")
@@ -396,11 +397,20 @@ def main():
     for _ in range(a.warmup):
         trainer.step()
     sync()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if a.step_times else None
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    if step_ev:
+        step_ev[0].record()
+    for k in range(a.steps):
         trainer.step()
+        if step_ev:
+            step_ev[k + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    if step_ev:   # diagnostic: where inside the timed region the time went (GPU-side interval between consecutive steps' last kernels)
+        iv = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(a.steps)]
+        order = sorted(range(a.steps), key=lambda k: -iv[k])[:3]
+        sys.stderr.write("step intervals (ms): median %.3f; slowest %s\n" % (sorted(iv)[len(iv) // 2], ", ".join("#%d %.3f" % (k, iv[k]) for k in order)))
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
