@@ -975,6 +975,57 @@ def test_deep_level_split_k_kernels_match_the_halo_tile_kernels_in_the_network(t
     assert abs(np.linalg.norm(d1) - np.linalg.norm(d0)) <= 5e-2 * np.linalg.norm(d0)
 
 
+_DEEP_BNORM_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import unet_studio_amd as U
+arch = ("conv32,ks3,stride1+bnorm,leaky_relu+conv32,ks3,stride1+bnorm,leaky_relu\n"
+        "conv64,ks3,stride2+bnorm,leaky_relu+conv64,ks3,stride1+bnorm,leaky_relu+conv_trans32,ks2,stride2\n"
+        "conv32,ks3,stride1+bnorm,leaky_relu+conv32,ks3,stride1+bnorm,leaky_relu+conv6,ks1,stride1")
+m = U.UNet3d(1, 6, arch, device="cuda:0", dtype="bf16", seed=0)
+feed = U.SyntheticVolumes(1, 6, (8, 8, 8), "cuda:0", cache=2)
+for k in range(2):                       # two training micro-steps: the running statistics move twice
+    x, t = feed(k)
+    m.forward_backward(x, t)
+torch.cuda.synchronize()
+bufs = np.concatenate([b.detach().float().cpu().numpy().ravel() for b in m.buffers()])
+m.eval()
+with torch.no_grad():
+    outs = m.forward(feed(0)[0])         # eval(): bnorm normalises with the running statistics (train.cpp:834-852)
+torch.cuda.synchronize()
+np.savez(sys.argv[2], grads=m.flat_grads.cpu().numpy(), bufs=bufs, **{"out%d" % k: o.float().cpu().numpy() for k, o in enumerate(outs)})
+"""
+
+
+def test_deep_level_kernels_with_bnorm_running_statistics_and_eval_forward(tmp_path):
+    """The norm epilogue of k_deep_conv also owns BatchNorm3d's bookkeeping (unet.cpp:80-84): in training it updates the running mean /
+    unbiased variance (momentum 0.1), in eval() it normalises with them (scale / shift from the running statistics, no batch
+    statistics).  A two-level bnorm network at 8^3 (coarse level 4^3: the fused path), two training micro-steps, then an eval forward --
+    against the same run with UNET_NO_DEEP_KERNELS=1 (k_norm_finalize_apply8 / k_norm_eval): buffers to summation order, eval logits and
+    gradients to bf16 rounding flips."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env_extra in (("deep", {}), ("halo", {"UNET_NO_DEEP_KERNELS": "1"})):
+        path = str(tmp_path / ("bn_%s.npz" % tag))
+        out = subprocess.run([sys.executable, "-c", _DEEP_BNORM_CHILD, root, path], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env_extra))
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[tag] = np.load(path)
+    a, b = res["deep"], res["halo"]
+    assert np.abs(a["grads"] - b["grads"]).max() > 0, "the switch did not reach the engine"
+    # running statistics: fp32 sums over 64 voxels in another order, then the values downstream of the first fused layer move by bf16
+    # rounding flips of its output
+    assert np.abs(a["bufs"] - b["bufs"]).max() <= 2e-2 * np.abs(b["bufs"]).max()
+    assert np.isfinite(a["bufs"]).all() and np.isfinite(a["grads"]).all()
+    outs = [k for k in a.files if k.startswith("out")]
+    assert "out0" in outs
+    for k in outs:
+        assert rel(a[k], b[k]) < 3e-2, k
+    assert abs(np.linalg.norm(a["grads"]) - np.linalg.norm(b["grads"])) <= 5e-2 * np.linalg.norm(b["grads"])
+
+
 def test_halo_tile_kernels_still_match_the_oracle():
     """UNET_NO_SLIDING_WINDOW=1 (mfma_util.h) is the documented fallback of every kernel that counts its vector-memory operations by
     hand (k_mfma_conv_z / _z16 / _z32, k_mfma_wgrad_z / _zd, k_s2_*): all shapes then run on the halo-tile kernels k_mfma_conv_p /
