@@ -321,8 +321,8 @@ __global__ void __launch_bounds__(256) k_deep_conv(DeepArgs a) {
     const ConvGeom& g = a.c.g;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, gq = lane >> 4;
     const int NTT = g.Cout / 16, NG = NTT / NTW, NGK = NG * a.ksplit;
-    // blocks that read the same filter slice (same row tiles and K range, different voxel group) are NGK apart: the same XCD (NGK % 8 == 0
-    // whenever MG > 1 matters: the launcher keeps NG * ksplit a multiple of 8 there), one HBM read of the slice per XCD at most
+    // blocks that read the same filter slice (same row tiles and K range, different voxel group) are NGK apart in the grid: with NGK a
+    // multiple of 8 (16+ row tiles or a K split of 8+: every shape of the default architecture) they share an XCD and its L2
     const int ngk = blockIdx.x % NGK, mg = blockIdx.x / NGK, ng = ngk % NG, ksp = ngk / NG;
     const int KS = T * a.nchunk;
     const int k0 = ksp * a.kper, k1 = k0 + a.kper < KS ? k0 + a.kper : KS;
@@ -448,11 +448,10 @@ static bool deep_off() {
     static const bool off = getenv("UNET_NO_DEEP_KERNELS") != nullptr;
     return off || sliding_window_off();
 }
-// the K split: enough blocks to stream the filter from every CU, each wave keeping at least two k-steps, the partial tiles inside the scratch
-static int deep_ksplit(int KS, int MG, int NG, int NTT, int Vpad, bool norm, const DeepScratch& sc) {
+// the K split: enough blocks to stream the filter from every CU, the partial tiles inside the scratch
+static int deep_ksplit(int KS, int MG, int NG, int NTT, int Vpad, const DeepScratch& sc) {
     // a wave's share of K in at most two rounds of its 4-deep prefetch (each round is one exposed memory latency), with up to 1024
     // blocks and 4 MB of partial tiles; small grids go on splitting down to one round per wave
-    (void)norm;
     const size_t cap = sc.part_bytes < ((size_t)4 << 20) ? sc.part_bytes : ((size_t)4 << 20);
     auto fits = [&](int k) { return k <= 32 && (int64_t)MG * NG * k <= 1024 && (size_t)k * NTT * Vpad * 16 * 4 <= cap; };
     int ks = 1;
@@ -470,7 +469,7 @@ static bool deep_launch(MfmaConvArgs c, int epi, const DeepNormFwd* nf, const De
     const int T = KD * KD * KD, KS = T * a.nchunk, NTT = g.Cout / 16;
     const int ntw = (NTT % 2 == 0 && (int64_t)a.MG * (NTT / 2) >= 128) ? 2 : 1;   // two row tiles per block only when the grid stays wide
     const int NG = NTT / ntw;
-    a.ksplit = deep_ksplit(KS, a.MG, NG, NTT, a.Vpad, epi != DEEP_PLAIN, sc);
+    a.ksplit = deep_ksplit(KS, a.MG, NG, NTT, a.Vpad, sc);
     a.kper = (KS + a.ksplit - 1) / a.ksplit;
     a.ksplit = (KS + a.kper - 1) / a.kper;
     if ((size_t)a.ksplit * NTT * a.Vpad * 16 * 4 > sc.part_bytes) return false;
