@@ -397,6 +397,11 @@ def main():
     for _ in range(a.warmup):
         trainer.step()
     sync()
+    # the interpreter's cyclic garbage collector stays out of the timed region (a full collection of a torch process's heap is a
+    # multi-millisecond host pause; the step allocates no cycles): collected before, re-enabled after
+    import gc
+    gc.collect()
+    gc.disable()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if a.step_times else None
     t0 = time.perf_counter()
     if step_ev:
@@ -407,6 +412,7 @@ def main():
             step_ev[k + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if step_ev:   # diagnostic: where inside the timed region the time went (GPU-side interval between consecutive steps' last kernels)
         iv = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(a.steps)]
         order = sorted(range(a.steps), key=lambda k: -iv[k])[:3]
