@@ -394,14 +394,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        trainer.step()
-    sync()
     # the interpreter's cyclic garbage collector stays out of the timed region (a full collection of a torch process's heap is a
-    # multi-millisecond host pause; the step allocates no cycles): collected before, re-enabled after
+    # multi-millisecond host pause; the step allocates no cycles): collected before the warm-up -- not between warm-up and timed steps,
+    # where the ~0.1 s it takes leaves the GPU idle and the first timed steps run 0.1-0.3 ms long while it clocks up again -- re-enabled after
     import gc
     gc.collect()
     gc.disable()
+    for _ in range(a.warmup):
+        trainer.step()
+    sync()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if a.step_times else None
     t0 = time.perf_counter()
     if step_ev:
