@@ -538,6 +538,53 @@ ARCH_MIX_NC = ("conv8,ks3,stride1+norm,elu+conv8,ks3,stride1+norm,leaky_relu\n"
                "conv8,ks3,stride1+norm,leaky_relu+conv5,ks1,stride1")
 
 
+ARCH_DEEP2 = ("conv32,ks3,stride1+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu\n"
+              "conv64,ks3,stride2+norm,leaky_relu+conv64,ks3,stride1+norm,leaky_relu+conv_trans32,ks2,stride2\n"
+              "conv32,ks3,stride1+norm,leaky_relu+conv32,ks3,stride1+norm,leaky_relu+conv5,ks1,stride1")
+
+
+@pytest.mark.parametrize("norm", ["norm", "bnorm"])
+@pytest.mark.parametrize("size", [(8, 8, 8), (12, 8, 10), (16, 16, 16)])
+def test_deep_level_kernels_network_against_live_aten(size, norm):
+    """kernels_mfma_deep.hip against the ATen CPU executor run live in float64: a two-level network of 32 / 64 channels whose coarse
+    level is 4^3 (every kind of the path incl. both norm epilogues), 6x4x5 (120 voxels: a ragged last 64-voxel group, odd extents under
+    the stride-2 conv and the conv_trans) or 8^3 (the short kinds only), with InstanceNorm3d and with BatchNorm3d (eps 0, running
+    statistics).  bf16 against fp64: the bounds of test_noncubic_network_against_live_aten's bf16 row, gradients a little wider (64-voxel
+    norms: measured values are printed)."""
+    arch = ARCH_DEEP2.replace("norm", norm)
+    torch.manual_seed(5)
+    ref = A.UNet3dRef(2, 5, arch)
+    ref.train()
+    x, t = A.synthetic_sample(2, 5, size, 13)
+    m = U.UNet3d(2, 5, arch, device=DEV, dtype="bf16")
+    m.load_parameters([p.detach().numpy() for p in ref.parameters()])
+    ref = ref.double()
+    outs_ref = ref(x.double())
+    loss_ref, _ = A.deep_supervision_loss(outs_ref, t, 5)
+    loss_ref.backward()
+    xd, td = x.to(DEV), t.to(DEV)
+    plan = m.plan_for(xd.shape[2:]); ws = m._workspace(plan)
+    outs = m._run_forward(plan, ws, xd, 1)
+    errs = []
+    for k, (o, r) in enumerate(zip(outs, outs_ref)):
+        e = rel(o[0].cpu().numpy().astype(np.float64), r[0].detach().numpy())
+        errs.append(e)
+        assert e < 8e-2, "logits level %d: %g" % (k, e)
+    losses, gouts = m.loss(outs, td)
+    assert abs(float(losses[0]) - float(loss_ref)) < 2e-2 * float(loss_ref)
+    m._run_backward(plan, ws, gouts)
+    gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).numpy()
+    g = m.flat_grads.cpu().numpy().astype(np.float64)
+    e = np.abs(g - gref).max() / np.abs(gref).max()
+    print("deep-level network %s %s: logits %s, gradients %.6g of the largest" % (size, norm, ", ".join("%.6g" % v for v in errs), e))
+    assert e < 0.25, "gradients: %g" % e
+    if norm == "bnorm":     # the running statistics the training forward moved (momentum 0.1, unbiased variance)
+        rbufs = [r for r in ref.buffers() if r.dtype.is_floating_point]     # running_mean / running_var (num_batches_tracked is host-side)
+        assert len(rbufs) == len(m.buffers()) > 0
+        for i, (b, r) in enumerate(zip(m.buffers(), rbufs)):
+            assert rel(b.float().cpu().numpy(), r.detach().float().numpy()) < 3e-2, "buffer %d" % i
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("size", [(24, 40, 56), (20, 36, 12), (8, 16, 132), (12, 20, 28, "mix")])
 def test_noncubic_network_against_live_aten(size, dt):
