@@ -88,6 +88,11 @@ CONV_CASES = [  # cin, cout, (D,H,W), ks, stride
     # ... and their sliding-window weight gradient (kernels_mfma_s2_wgrad.hip; output >= 24 wide): (ca, cb) pairings 1x2 / 2x2 / 2x1, several
     # pair groups, ragged 32-voxel K-steps, odd input sizes, z segments of unequal length
     (16, 32, (9, 12, 64), 3, 2), (32, 32, (12, 9, 50), 3, 2), (32, 16, (8, 8, 48), 3, 2), (16, 64, (21, 7, 70), 3, 2),
+    # split-K kernels of the deep levels (kernels_mfma_deep.hip; bf16, Cin % 32 == 0): 27-tap kinds at <= 64 output voxels (ragged
+    # last 64-voxel group, one- and two-voxel extents, K splits of 8..32, one and two row tiles per block), stride 2 from odd extents,
+    # and their dgrads (stride-2 dgrad up to a 512-voxel coarse grid)
+    (64, 48, (3, 4, 5), 3, 1), (128, 32, (2, 2, 2), 3, 1), (512, 64, (1, 2, 3), 3, 1), (32, 128, (4, 4, 3), 3, 1),
+    (32, 64, (7, 6, 5), 3, 2), (128, 128, (8, 8, 8), 3, 2), (64, 32, (3, 2, 2), 3, 2), (32, 32, (13, 15, 16), 3, 2),
     # fp32 matrix-core conv (fp32 engine, volumes >= 4096 voxels): NT 1 / 2, ragged tile edges in z, y and x, 8-channel chunk tail
     (16, 16, (16, 16, 32), 3, 1), (32, 64, (17, 19, 21), 3, 1), (24, 48, (9, 23, 22), 3, 1), (64, 32, (18, 17, 16), 3, 1),
 ]
@@ -210,6 +215,8 @@ def test_conv3d_fused_prologue_epilogue(case, dt, impl):
                                   (32, 48, (8, 8, 8)),
                                   # conv_trans dgrad with 32-channel chunks (Cout % 32 == 0 on coarse grids of 8^3 or less): both tiles
                                   (64, 64, (5, 6, 7)), (32, 96, (8, 8, 8)), (256, 256, (4, 4, 4)),
+                                  # split-K kernels of the deep levels (coarse grids of <= 512 voxels, Cin % 32 == 0): ragged groups, one-voxel extents
+                                  (64, 32, (3, 3, 5)), (32, 16, (1, 2, 3)), (256, 128, (2, 2, 2)), (96, 64, (7, 8, 8)),
                                   # sliding-window conv_trans kernels (kernels_mfma_s2.hip; coarse grid >= 16 wide, >= 4 deep): forward with 1 / 2 / 4
                                   # k-steps and 1..4 row-tile blocks, dgrad with 16- and 32-channel planes and 2 / 4 row tiles per block, ragged edges
                                   (32, 16, (4, 6, 16)), (64, 32, (5, 9, 19)), (128, 64, (4, 4, 16)), (32, 48, (6, 7, 17)), (64, 16, (7, 5, 20)),
